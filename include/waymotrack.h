@@ -1,0 +1,157 @@
+/* libwaymotrack - C ABI of the MI355X-native detect -> ensemble -> SORT hot path.
+ *
+ * The reference (xuyuan/waymo_2d_tracking) is pure Python and has no FFI layer: its "operator API" is a
+ * set of Python call signatures.  Each entry point below replaces one of those
+ * call sites; the Python shims in waymo_2d_tracking_amd/ keep the reference's names and argument
+ * meaning and reach this library through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions: C linkage, plain pointers and sizes, no exceptions; every function returns an int status
+ * (WT_OK == 0) and wt_last_error() gives the message of the calling thread's last failure.  All compute
+ * runs in HIP kernels on the current HIP device (gfx950); there is NO CPU fallback: without a usable GPU
+ * the functions return WT_ERR_NO_DEVICE.
+ *   *_host entry points take host buffers (they stage through device memory internally);
+ *   *_dev  entry points take device pointers plus a hipStream_t (passed as void*), never synchronise,
+ *          and use only caller-provided workspace (query the size with the matching *_workspace call).
+ * Paths below are relative to the reference repository root.
+ */
+#ifndef WAYMOTRACK_H
+#define WAYMOTRACK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WT_OK 0
+#define WT_ERR_INVALID 1    /* bad argument */
+#define WT_ERR_NO_DEVICE 2  /* no HIP device / wrong architecture */
+#define WT_ERR_HIP 3        /* HIP runtime error */
+#define WT_ERR_CAPACITY 4   /* caller buffer or workspace too small */
+#define WT_ERR_NUMERIC 5    /* iteration guard hit inside a kernel (e.g. NaN cost matrix) */
+
+const char* wt_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int wt_abi_version(void);
+/* Number of visible HIP devices and name/arch of the current one ("gfx950..."). */
+int wt_device_info(int* n_devices, char* arch, int arch_cap, int* n_cu);
+
+/* =================================================================================================
+ * SORT  (tracking/sort/sort.py, tracking/sort/tracker_sort.py, tracking/utils.py)
+ * ================================================================================================= */
+
+/* Process-global track-ID counter: KalmanBoxTracker.count (tracking/sort/sort.py:86,140-141). */
+typedef struct wt_idctr wt_idctr;
+wt_idctr* wt_idctr_create(int64_t start);
+int64_t wt_idctr_get(const wt_idctr* c);
+void wt_idctr_set(wt_idctr* c, int64_t value);
+void wt_idctr_destroy(wt_idctr* c);
+
+/* Sort(max_age, min_hits) - tracking/sort/sort.py:234-242.  State lives in device memory.
+ * ctr may be NULL (private counter starting at 0). */
+typedef struct wt_sort wt_sort;
+int wt_sort_create(int max_age, int min_hits, wt_idctr* ctr, wt_sort** out);
+void wt_sort_destroy(wt_sort* s);
+/* Sort.update(dets, iou_threshold) - tracking/sort/sort.py:244-296.
+ * dets5: (n,5) float32 rows [x1,y1,x2,y2,score] (n may be 0: "must be called once per frame even with empty
+ * detections", :248).  out6: up to cap rows [x1,y1,x2,y2,id+1,confidence] float64, newest track first. */
+int wt_sort_update_host(wt_sort* s, const float* dets5, int n, double iou_threshold,
+                        double* out6, int cap, int* n_out);
+/* Debug/test hook: current track list in list order (ids, state x[7], covariance P[49], row-major). */
+int wt_sort_state_host(wt_sort* s, int cap, int64_t* ids, double* x7, double* P49, int* n_tracks);
+
+/* associate_detections_to_trackers(detections, trackers, iou_threshold) - tracking/sort/sort.py:193-230
+ * (IoU matrix :33-47,201-205 + sklearn 0.22.2 linear_assignment :206 + threshold filter :218-224).
+ * dets5 (n,5) f32, trks4 (t,4) f64.  matches: (det,trk) pairs sorted by det; unmatched lists in the
+ * reference's order.  Buffers: matches 2*min(n,t), unmatched_dets n, unmatched_trks t ints. */
+int wt_associate_host(const float* dets5, int n, const double* trks4, int t, double iou_threshold,
+                      int* matches, int* n_matches, int* unmatched_dets, int* n_unmatched_dets,
+                      int* unmatched_trks, int* n_unmatched_trks);
+
+/* linear_assignment(X) of scikit-learn 0.22.2 (call site tracking/sort/sort.py:206) on a float32 cost matrix
+ * (n_rows x n_cols, row-major).  pairs: (row,col) sorted by row, 2*min(n_rows,n_cols) ints. */
+int wt_linear_assignment_f32_host(const float* cost, int n_rows, int n_cols, int* pairs, int* n_pairs);
+
+/* Batched tracking of every (segment,camera) stream of a detections file:
+ * read_data_file filters (tracking/utils.py:79,86) + track_sort (tracking/utils.py:25-60) +
+ * MultiClassTrackerSort.track (tracking/sort/tracker_sort.py:22-51) in the stream order of
+ * tracking/track.py:43-47, including the global ID order of tracking/sort/sort.py:86.
+ *
+ * Detections are SoA, sorted by (stream, frame) with the input order preserved inside a frame:
+ *   x,y,w,h,score float64 (JSON numbers), category int32 in 1..n_classes.
+ * frame_det_offsets (n_frames+1) and stream_frame_offsets (n_streams+1) are CSR offsets; frames of a stream
+ * are in ascending frame-id order; a frame whose detections are all filtered still ticks the trackers.
+ * clip_w/clip_h: per-stream image size (tracking/utils.py:11-22); <= 0 disables clipping, the w/h<1 drop and
+ * the confidence clip.  score_threshold / iou_threshold: n_classes entries indexed by category-1.
+ * id_base: value of the global ID counter before this call (rank offset in multi-GPU runs).
+ * Outputs hold at most n_dets rows, in the reference's output order:
+ *   out_frame (global frame index), out_category, out_bbox4 [x1,y1,w,h], out_score, out_object_id.
+ * n_births = number of track IDs consumed. */
+typedef struct wt_track_params {
+    int32_t max_age;
+    int32_t min_hits;
+    int32_t n_classes;
+    int32_t reserved;
+    const double* score_threshold;   /* host pointers, n_classes entries */
+    const double* iou_threshold;
+} wt_track_params;
+
+int wt_track_streams_host(int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
+                          const double* score, const int32_t* category,
+                          int64_t n_frames, const int64_t* frame_det_offsets,
+                          int32_t n_streams, const int64_t* stream_frame_offsets,
+                          const double* clip_w, const double* clip_h,
+                          const wt_track_params* params, int64_t id_base,
+                          int64_t* out_frame, int32_t* out_category, double* out_bbox4, double* out_score,
+                          int64_t* out_object_id, int64_t* n_out, int64_t* n_births);
+
+/* Device-resident form.  All array arguments are device pointers except params (host struct with host
+ * threshold arrays) ; max_frame_dets = max detections in any frame (sizes the per-tracker state).
+ * n_out_dev / n_births_dev: device int64 scalars.  Stream-ordered on `stream`; no host synchronisation. */
+size_t wt_track_streams_workspace(int64_t n_dets, int64_t n_frames, int32_t n_streams, int64_t max_frame_dets,
+                                  const wt_track_params* params);
+int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
+                         const double* score, const int32_t* category,
+                         int64_t n_frames, const int64_t* frame_det_offsets,
+                         int32_t n_streams, const int64_t* stream_frame_offsets,
+                         const double* clip_w, const double* clip_h, int64_t max_frame_dets,
+                         const wt_track_params* params, int64_t id_base,
+                         int64_t* out_frame, int32_t* out_category, double* out_bbox4, double* out_score,
+                         int64_t* out_object_id, int64_t* n_out_dev, int64_t* n_births_dev,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* =================================================================================================
+ * soft-NMS / NMS / weighted-fusion ensemble
+ * (detnet/utils/box_utils.py, detnet/nn/tta.py, detnet/ensemble.py)
+ * ================================================================================================= */
+
+/* nms(boxes, scores, overlap, top_k, soft=True, conf_thresh, soft_nms_cut) - detnet/utils/box_utils.py:307-395.
+ * boxes4 (n,4) xyxy float64.  keep: kept indices in descending original-score order, out_scores: decayed
+ * scores; both need n entries. */
+int wt_softnms_f64_host(const double* boxes4, const double* scores, int n, double overlap, double cut,
+                        double conf_thresh, int top_k, int64_t* keep, double* out_scores, int* n_keep);
+/* Hard branch (detnet/utils/box_utils.py:329-333 -> torchvision.ops.nms): greedy, IoU > overlap suppresses. */
+int wt_hardnms_f64_host(const double* boxes4, const double* scores, int n, double overlap, int top_k,
+                        int64_t* keep, double* out_scores, int* n_keep);
+
+/* ensemble(image_id, detections, category_ids) - detnet/ensemble.py:50-64 - for G (image,category) groups at
+ * once: lxly2cxcy (:19-22) -> merge_func -> cxcy2lxly (:25-28).  Rows are [score,x_left,y_top,w,h] float64.
+ *   method 0: merge_detections weighted fusion (detnet/nn/tta.py:22-66)
+ *   method 1: nms_detections hard NMS          (detnet/nn/tta.py:8-19, soft=False)
+ *   method 2: nms_detections linear soft-NMS   (detnet/nn/tta.py:8-19, soft=True, soft_nms_cut)
+ * group_offsets (G+1) rows CSR; inside a group rows are the K inputs concatenated in input-file order and
+ * input_sizes (G*K) gives the rows each input contributed (only method 0 reads it; may be NULL otherwise).
+ * out5 has the input's row capacity: group g writes out_counts[g] rows starting at row group_offsets[g].
+ * The min_score filter / astype(int) / round(score,5) of ensemble.py:59-62 is left to the caller. */
+int wt_ensemble_groups_host(const double* dets5, const int64_t* group_offsets, const int32_t* input_sizes,
+                            int64_t n_groups, int k_inputs, int method, double iou_thresh, double soft_nms_cut,
+                            double* out5, int64_t* out_counts);
+size_t wt_ensemble_groups_workspace(int64_t n_rows, int64_t n_groups, int64_t max_group_rows);
+int wt_ensemble_groups_dev(const double* dets5, const int64_t* group_offsets, const int32_t* input_sizes,
+                           int64_t n_rows, int64_t n_groups, int64_t max_group_rows, int k_inputs, int method,
+                           double iou_thresh, double soft_nms_cut, double* out5, int64_t* out_counts,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
