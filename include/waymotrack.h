@@ -56,6 +56,8 @@ void wt_sort_destroy(wt_sort* s);
  * detections", :248).  out6: up to cap rows [x1,y1,x2,y2,id+1,confidence] float64, newest track first. */
 int wt_sort_update_host(wt_sort* s, const float* dets5, int n, double iou_threshold,
                         double* out6, int cap, int* n_out);
+/* Number of live tracks (len(self.trackers)) after the last update. */
+int wt_sort_num_tracks(const wt_sort* s);
 /* Debug/test hook: current track list in list order (ids, state x[7], covariance P[49], row-major). */
 int wt_sort_state_host(wt_sort* s, int cap, int64_t* ids, double* x7, double* P49, int* n_tracks);
 
@@ -138,6 +140,8 @@ int wt_hardnms_f64_host(const double* boxes4, const double* scores, int n, doubl
  *   method 0: merge_detections weighted fusion (detnet/nn/tta.py:22-66)
  *   method 1: nms_detections hard NMS          (detnet/nn/tta.py:8-19, soft=False)
  *   method 2: nms_detections linear soft-NMS   (detnet/nn/tta.py:8-19, soft=True, soft_nms_cut)
+ *   method | 16: rows are [score,cx,cy,w,h] on input and output, i.e. the bare merge_func call signature of
+ *                detnet/nn/tta.py:8,22 without the ensemble.py:19-28 conversions.
  * group_offsets (G+1) rows CSR; inside a group rows are the K inputs concatenated in input-file order and
  * input_sizes (G*K) gives the rows each input contributed (only method 0 reads it; may be NULL otherwise).
  * out5 has the input's row capacity: group g writes out_counts[g] rows starting at row group_offsets[g].

@@ -1,0 +1,76 @@
+"""In-tree build of libwaymotrack.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m waymo_2d_tracking_amd.build [--force]
+
+Each .hip translation unit is compiled to an object (in parallel) and linked into
+waymo_2d_tracking_amd/csrc/libwaymotrack.so.  The tracking / ensemble units are built with
+-ffp-contract=off because their results must be bit-identical to the reference's elementwise float64 / float32
+arithmetic; the detector kernels keep FMA contraction.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libwaymotrack.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-Wall', '-Wno-unused-function']
+# unit -> extra flags
+UNITS = {
+    'api.hip': [],
+    'ensemble.hip': ['-ffp-contract=off'],
+    'sort_engine.hip': ['-ffp-contract=off'],
+    'sort_single.hip': ['-ffp-contract=off'],
+    'det_roialign.hip': [],
+    'det_nms.hip': [],
+    'det_deform.hip': [],
+    'det_gemm.hip': [],
+    'det_misc.hip': [],
+}
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=True):
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers += [os.path.join(HERE, '..', 'include', f) for f in os.listdir(os.path.join(HERE, '..', 'include'))]
+    units = [u for u in UNITS if os.path.exists(os.path.join(CSRC, u))]
+    objs = []
+    jobs = []
+    for u in units:
+        src = os.path.join(CSRC, u)
+        obj = os.path.join(CSRC, u.replace('.hip', '.o'))
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            jobs.append([HIPCC] + COMMON + UNITS[u] + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stderr[-6000:]))
+        if verbose and r.stderr.strip():
+            print(r.stderr[-3000:])
+        return 0
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _newer(LIB, objs):
+        run([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,61 @@
+// libwaymotrack internal helpers (host side).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/waymotrack.h"
+
+namespace wt {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+int ensure_device();               // WT_OK when a gfx950 device is current and usable
+
+#define WT_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return ::wt::hip_fail(e__, #call);      \
+    } while (0)
+
+#define WT_TRY(call)                 \
+    do {                             \
+        int rc__ = (call);           \
+        if (rc__ != WT_OK) return rc__; \
+    } while (0)
+
+// RAII device allocation for the *_host entry points
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return hip_fail(e, "hipMalloc"); }
+        return WT_OK;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// carve typed arrays out of one workspace block
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base(reinterpret_cast<char*>(b)) {}
+    template <class T> T* take(size_t count) {
+        T* r = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off += align_up(count * sizeof(T));
+        return r;
+    }
+};
+
+}  // namespace wt

@@ -1,0 +1,550 @@
+// Device-side SORT building blocks for gfx950: one 64-lane wavefront owns one tracker (one class of one
+// (segment, camera) stream).  Mirrors, bit for bit, the arithmetic order of the reference path
+//   tracking/sort/sort.py (KalmanBoxTracker :78-190, iou :33-47, associate :193-230, Sort.update :244-296)
+// with filterpy's KalmanFilter and scikit-learn 0.22.2's Munkres restated (oracle/sort_oracle.c is the CPU twin).
+// Compile with -ffp-contract=off: products and sums are rounded one by one, k ascending, like the oracle.
+//
+// Layout: Kalman state is SoA in global memory (element e of slot s at e*cap + s) so a wave's 64 tracks read
+// 64 consecutive doubles per element; the float32 cost matrix and the Munkres cover/star arrays live in LDS
+// (global scratch when N*T exceeds the LDS budget); lists are compacted with ballot + popcount prefix sums.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace wtdev {
+
+constexpr int kWave = 64;
+constexpr int kErrCapacity = 4;   // WT_ERR_CAPACITY
+constexpr int kErrNumeric = 5;    // WT_ERR_NUMERIC
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+__device__ __forceinline__ bool finite_d(double v) { return (v == v) && (v - v == 0.0); }
+
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float u = __shfl_xor(v, o, kWave);
+        v = (u < v) ? u : v;
+    }
+    return v;
+}
+
+// ---- sort.py:33-47 iou(float32 detection, float64 track) under NumPy-1.x scalar promotion -----------------
+__device__ __forceinline__ double iou_det_trk(const float d[4], const double t[4]) {
+    const double d0 = (double)d[0], d1 = (double)d[1], d2 = (double)d[2], d3 = (double)d[3];
+    const double xx1 = (d0 > t[0]) ? d0 : t[0];
+    const double yy1 = (d1 > t[1]) ? d1 : t[1];
+    const double xx2 = (d2 < t[2]) ? d2 : t[2];
+    const double yy2 = (d3 < t[3]) ? d3 : t[3];
+    double w = xx2 - xx1; if (!(w > 0.)) w = (w != w) ? w : 0.;
+    double h = yy2 - yy1; if (!(h > 0.)) h = (h != h) ? h : 0.;
+    const double wh = w * h;
+    const float dw = d[2] - d[0];
+    const float dh = d[3] - d[1];
+    const float darea = dw * dh;                                   // float32 product (sort.py:44)
+    const double tarea = (t[2] - t[0]) * (t[3] - t[1]);
+    return wh / (((double)darea + tarea) - wh);
+}
+
+// ---- sort.py:50-62 / :65-75 -------------------------------------------------------------------------------
+__device__ __forceinline__ void bbox_to_z(const float b[4], double z[4]) {
+    const float w = b[2] - b[0];
+    const float h = b[3] - b[1];
+    z[0] = (double)b[0] + (double)w / 2.;
+    z[1] = (double)b[1] + (double)h / 2.;
+    const float s = w * h;                                          // float32 area
+    z[2] = (double)s;
+    z[3] = (double)w / (double)h;
+}
+
+__device__ __forceinline__ void x_to_bbox(double x0, double x1, double x2, double x3, double b[4]) {
+    const double w = sqrt(x2 * x3);
+    const double h = x2 / w;
+    b[0] = x0 - w / 2.;
+    b[1] = x1 - h / 2.;
+    b[2] = x0 + w / 2.;
+    b[3] = x1 + h / 2.;
+}
+
+// Q, R, P0 of sort.py:111-115,127,133-134
+__device__ __forceinline__ double kq(int i) { return i < 2 ? 2. : (i == 2 ? 1. : (i == 3 ? 25. : (i == 6 ? 5. : 4.))); }
+__device__ __forceinline__ double kr(int i) { return i < 2 ? 1. : 10.; }
+__device__ __forceinline__ double kp0(int i) { return i < 4 ? 10. : 10000.; }
+
+struct TrackerMem {
+    double* kx;      // [7][cap]   state, by slot
+    double* kP;      // [49][cap]  covariance, by slot
+    double* pbox;    // [4][cap]   predicted boxes, by list position
+    long long* gid;  // [cap] id assigned at birth (single-tracker API: the global id)
+    int* tsu;        // time_since_update, by slot
+    int* streak;     // hit_streak, by slot
+    int* bframe;     // birth frame (global frame index), by slot
+    int* bk;         // birth rank inside (frame, class), by slot
+    int* order;      // list position -> slot   (the python list self.trackers)
+    int* freel;      // free-slot stack
+    int* trk_match;  // by list position: matched detection or -1
+    int* det_match;  // by detection: list position, -1 never assigned, -2 assigned but rejected by the threshold
+    int* new_list;   // unmatched detections in the reference's order
+    float* cost_g;   // global cost scratch (capN x cap), used when the matrix does not fit in LDS
+    int cap;         // max tracks
+    int capN;        // max detections per frame
+};
+
+struct TrackerState {   // wave-uniform
+    int n_tracks;
+    int n_free;
+    int frame_count;
+    int next_local;
+};
+
+// ---- predict (sort.py:166-178 + filterpy predict): x = Fx, P = F P F^T + Q --------------------------------
+__device__ __forceinline__ void kalman_predict(const TrackerMem& M, int slot, double box[4]) {
+    const int cap = M.cap;
+    double x[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = M.kx[i * cap + slot];
+    if ((x[6] + x[2]) <= 0) x[6] *= 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x[i] = x[i] + x[i + 4];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) M.kx[i * cap + slot] = x[i];
+    // P: rows 0..2 get rows 4..6 added (F P), then columns 0..2 get columns 4..6 added ((FP) F^T), then + Q
+    double P[49];
+#pragma unroll
+    for (int e = 0; e < 49; ++e) P[e] = M.kP[e * cap + slot];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) P[i * 7 + j] = P[i * 7 + j] + P[(i + 4) * 7 + j];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) P[i * 7 + j] = P[i * 7 + j] + P[i * 7 + j + 4];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) P[i * 7 + i] = P[i * 7 + i] + kq(i);
+#pragma unroll
+    for (int e = 0; e < 49; ++e) M.kP[e * cap + slot] = P[e];
+    x_to_bbox(x[0], x[1], x[2], x[3], box);
+}
+
+// numpy.linalg.inv on 4x4: LU with partial pivoting + per-column solves (same order as oracle inv4)
+__device__ __forceinline__ void inv4(const double S[16], double SI[16]) {
+    double A[16];
+    int piv[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) A[e] = S[e];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        double best = fabs(A[k * 4 + k]);
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            const double v = fabs(A[i * 4 + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        piv[k] = p;
+        if (p != k) {
+#pragma unroll
+            for (int i = k + 1; i < 4; ++i) {       // static indexing only: swap row k with row i when i == p
+                if (i == p) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const double tmp = A[k * 4 + j]; A[k * 4 + j] = A[i * 4 + j]; A[i * 4 + j] = tmp; }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            A[i * 4 + k] = A[i * 4 + k] / A[k * 4 + k];
+#pragma unroll
+            for (int j = k + 1; j < 4; ++j) A[i * 4 + j] = A[i * 4 + j] - A[i * 4 + k] * A[k * 4 + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double b[4] = {0., 0., 0., 0.};
+        b[j] = 1.;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int i = k + 1; i < 4; ++i)
+                if (piv[k] == i) { const double tmp = b[k]; b[k] = b[i]; b[i] = tmp; }
+        }
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < i; ++k) b[i] = b[i] - A[i * 4 + k] * b[k];
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+#pragma unroll
+            for (int k = i + 1; k < 4; ++k) b[i] = b[i] - A[i * 4 + k] * b[k];
+            b[i] = b[i] / A[i * 4 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) SI[i * 4 + j] = b[i];
+    }
+}
+
+// ---- update (sort.py:153-164 + filterpy update, Joseph form) ----------------------------------------------
+__device__ __forceinline__ void kalman_update(const TrackerMem& M, int slot, const float det[4]) {
+    const int cap = M.cap;
+    double z[4], y[4], S[16], SI[16], K[28], P[49];
+    bbox_to_z(det, z);
+#pragma unroll
+    for (int e = 0; e < 49; ++e) P[e] = M.kP[e * cap + slot];
+    double x[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) x[i] = M.kx[i * cap + slot];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = z[i] - x[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[i * 4 + j] = (i == j) ? (P[i * 7 + j] + kr(i)) : P[i * 7 + j];
+    inv4(S, SI);
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double acc = P[i * 7 + 0] * SI[0 * 4 + j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) acc = acc + P[i * 7 + k] * SI[k * 4 + j];
+            K[i * 4 + j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        double acc = K[i * 4 + 0] * y[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) acc = acc + K[i * 4 + k] * y[k];
+        M.kx[i * cap + slot] = x[i] + acc;
+    }
+    // A = I - K H  (only its first four columns differ from I);  B = A P;  P' = B A^T + (K R) K^T
+    double B[49];
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            double acc = (((i == 0) ? 1. : 0.) - K[i * 4 + 0]) * P[0 * 7 + j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) acc = acc + (((i == k) ? 1. : 0.) - K[i * 4 + k]) * P[k * 7 + j];
+            if (i >= 4) acc = acc + P[i * 7 + j];
+            B[i * 7 + j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            double acc = B[i * 7 + 0] * (((j == 0) ? 1. : 0.) - K[j * 4 + 0]);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) acc = acc + B[i * 7 + k] * (((j == k) ? 1. : 0.) - K[j * 4 + k]);
+            if (j >= 4) acc = acc + B[i * 7 + j];
+            double krk = (K[i * 4 + 0] * kr(0)) * K[j * 4 + 0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) krk = krk + (K[i * 4 + k] * kr(k)) * K[j * 4 + k];
+            M.kP[(i * 7 + j) * cap + slot] = acc + krk;
+        }
+}
+
+// ---- new track (sort.py:88-151) ---------------------------------------------------------------------------
+__device__ __forceinline__ void track_init(const TrackerMem& M, int slot, const float det[4]) {
+    const int cap = M.cap;
+    double z[4];
+    bbox_to_z(det, z);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) M.kx[i * cap + slot] = (i < 4) ? z[i] : 0.;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) M.kP[(i * 7 + j) * cap + slot] = (i == j) ? kp0(i) : 0.;
+}
+
+// ---- scikit-learn 0.22.2 Munkres (call site sort.py:206) on one wavefront ----------------------------------
+struct MunkresMem {       // LDS
+    int* row_star;        // [n]  column of the star in the row, -1 none
+    int* col_star;        // [m]
+    int* row_prime;       // [n]
+    unsigned char* row_cov;
+    unsigned char* col_cov;
+};
+
+// C: n x m float32 (n <= m), modified in place.  Returns 0, or 5 when the iteration guard trips.
+template <class CostPtr>
+__device__ int munkres_wave(CostPtr C, int n, int m, const MunkresMem& L) {
+    const int lane = threadIdx.x & 63;
+    for (int r = lane; r < n; r += kWave) { L.row_star[r] = -1; L.row_prime[r] = -1; L.row_cov[r] = 0; }
+    for (int c = lane; c < m; c += kWave) { L.col_star[c] = -1; L.col_cov[c] = 0; }
+    __syncthreads();
+    // step 1: subtract row minima; star the first zero of each row whose column is still free (row-major)
+    for (int r = 0; r < n; ++r) {
+        float mn = __builtin_inff();
+        for (int c = lane; c < m; c += kWave) { const float v = C[r * m + c]; mn = (v < mn) ? v : mn; }
+        mn = wave_min_f(mn);
+        int first = -1;
+        for (int base = 0; base < m; base += kWave) {
+            const int c = base + lane;
+            bool z = false;
+            if (c < m) {
+                const float v = C[r * m + c] - mn;
+                C[r * m + c] = v;
+                z = (v == 0.f) && !L.col_cov[c];
+            }
+            const unsigned long long mask = __ballot(z);
+            if (mask && first < 0) first = base + __builtin_ctzll(mask);
+        }
+        if (first >= 0 && lane == 0) { L.row_star[r] = first; L.col_star[first] = r; L.col_cov[first] = 1; }
+        __syncthreads();
+    }
+    long guard = 0;
+    const long guard_max = 64L + 8L * (long)(n + m) * (long)(n + m) * (long)(n + 1);
+    for (;;) {
+        // step 3
+        int stars = 0;
+        for (int base = 0; base < m; base += kWave) {
+            const int c = base + lane;
+            const bool st = (c < m) && L.col_star[c] >= 0;
+            if (c < m) L.col_cov[c] = st ? 1 : 0;
+            stars += __popcll(__ballot(st));
+        }
+        for (int r = lane; r < n; r += kWave) L.row_cov[r] = 0;
+        __syncthreads();
+        if (stars >= n) return 0;
+        // step 4 (+ step 6)
+        int z0r = -1, z0c = -1;
+        for (;;) {
+            if (++guard > guard_max) return 5;
+            int fr = -1, fc = -1;
+            for (int r = 0; r < n && fr < 0; ++r) {
+                if (L.row_cov[r]) continue;
+                for (int base = 0; base < m; base += kWave) {
+                    const int c = base + lane;
+                    const bool z = (c < m) && !L.col_cov[c] && (C[r * m + c] == 0.f);
+                    const unsigned long long mask = __ballot(z);
+                    if (mask) { fr = r; fc = base + __builtin_ctzll(mask); break; }
+                }
+            }
+            if (fr < 0) {
+                // step 6
+                float mn = __builtin_inff();
+                bool any_r = false;
+                for (int r = 0; r < n; ++r) {
+                    if (L.row_cov[r]) continue;
+                    any_r = true;
+                    for (int c = lane; c < m; c += kWave)
+                        if (!L.col_cov[c]) { const float v = C[r * m + c]; mn = (v < mn) ? v : mn; }
+                }
+                bool any_c = false;
+                for (int base = 0; base < m; base += kWave) {
+                    const int c = base + lane;
+                    any_c = any_c || (__ballot((c < m) && !L.col_cov[c]) != 0ull);
+                }
+                mn = wave_min_f(mn);
+                if (any_r && any_c) {
+                    for (int r = 0; r < n; ++r) {
+                        const bool rc = L.row_cov[r] != 0;
+                        for (int c = lane; c < m; c += kWave) {
+                            float v = C[r * m + c];
+                            if (rc) v = v + mn;
+                            if (!L.col_cov[c]) v = v - mn;
+                            C[r * m + c] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+            const int sc = uni(L.row_star[fr]);
+            if (lane == 0) L.row_prime[fr] = fc;
+            if (sc < 0) { z0r = fr; z0c = fc; break; }
+            if (lane == 0) { L.row_cov[fr] = 1; L.col_cov[sc] = 0; }
+            __syncthreads();
+        }
+        __syncthreads();
+        // step 5: augmenting path (serial, lane 0)
+        if (lane == 0) {
+            int pr = z0r, pc = z0c;
+            for (long it = 0; it <= (long)n + m; ++it) {
+                const int r2 = L.col_star[pc];
+                L.row_star[pr] = pc;
+                L.col_star[pc] = pr;
+                if (r2 < 0) break;
+                pr = r2;
+                pc = L.row_prime[r2];
+            }
+        }
+        __syncthreads();
+        for (int r = lane; r < n; r += kWave) L.row_prime[r] = -1;
+        __syncthreads();
+    }
+}
+
+// One frame of one tracker: sort.py:244-296.  Dets::get(k, float[4]) yields the k-th detection of this class
+// as the float32 row the reference builds (tracker_sort.py:45); Emit receives the rows of sort.py:286-288.
+template <class Dets, class Emit>
+__device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresMem& L, float* lds_cost,
+                            int lds_cost_cap, const Dets& dets, int N, double iou_thr, int max_age, int min_hits,
+                            int frame_global, long long id_base, Emit& emit, int* n_births, int* n_rows) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lanemask_lt();
+    const int cap = M.cap;
+    S.frame_count += 1;
+    // ---- predict; tracks with a non-finite predicted box are dropped (sort.py:256-265) ----
+    int T = 0;
+    {
+        const int T0 = S.n_tracks;
+        for (int base = 0; base < T0; base += kWave) {
+            const int i = base + lane;
+            const bool act = i < T0;
+            int slot = 0;
+            bool ok = false;
+            double b[4] = {0., 0., 0., 0.};
+            if (act) {
+                slot = M.order[i];
+                kalman_predict(M, slot, b);
+                const int tsu = M.tsu[slot];
+                if (tsu > 0) M.streak[slot] = 0;
+                M.tsu[slot] = tsu + 1;
+                ok = finite_d(b[0]) && finite_d(b[1]) && finite_d(b[2]) && finite_d(b[3]);
+            }
+            const unsigned long long good = __ballot(act && ok);
+            const unsigned long long bad = __ballot(act && !ok);
+            if (act && ok) {
+                const int np = T + __popcll(good & lt);
+                M.order[np] = slot;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) M.pbox[c * cap + np] = b[c];
+            }
+            if (act && !ok) M.freel[S.n_free + __popcll(bad & lt)] = slot;
+            T += __popcll(good);
+            S.n_free += __popcll(bad);
+        }
+    }
+    for (int i = lane; i < T; i += kWave) M.trk_match[i] = -1;
+    for (int k = lane; k < N; k += kWave) M.det_match[k] = -1;
+    __syncthreads();
+    // ---- associate (sort.py:193-230) ----
+    if (T > 0 && N > 0) {
+        const bool transposed = T < N;                 // Munkres works on rows <= cols
+        const int n = transposed ? T : N, m = transposed ? N : T;
+        const bool in_lds = (long)n * m <= (long)lds_cost_cap;
+        if (!in_lds && !M.cost_g) return kErrCapacity;
+        float* C = in_lds ? lds_cost : M.cost_g;
+        for (int r = 0; r < n; ++r) {
+            for (int c = lane; c < m; c += kWave) {
+                const int d = transposed ? c : r, t = transposed ? r : c;
+                float db[4];
+                dets.get(d, db);
+                double tb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tb[q] = M.pbox[q * cap + t];
+                const float v = (float)iou_det_trk(db, tb);          // stored float32 (sort.py:201,205)
+                C[r * m + c] = -v;                                     // linear_assignment(-iou_matrix)
+            }
+        }
+        __syncthreads();
+        const int rc = in_lds ? munkres_wave(lds_cost, n, m, L) : munkres_wave(M.cost_g, n, m, L);
+        if (rc) return rc;
+        for (int d = lane; d < N; d += kWave) {
+            const int t = transposed ? L.col_star[d] : L.row_star[d];
+            if (t >= 0) {
+                float db[4];
+                dets.get(d, db);
+                double tb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tb[q] = M.pbox[q * cap + t];
+                const float v = (float)iou_det_trk(db, tb);
+                if ((double)v < iou_thr) {                             // sort.py:220 (f32 value vs python float)
+                    M.det_match[d] = -2;
+                } else {
+                    M.det_match[d] = t;
+                    M.trk_match[t] = d;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- update matched tracks (sort.py:270-273) ----
+    for (int i = lane; i < T; i += kWave) {
+        const int d = M.trk_match[i];
+        if (d >= 0) {
+            const int slot = M.order[i];
+            float db[4];
+            dets.get(d, db);
+            M.tsu[slot] = 0;
+            M.streak[slot] = M.streak[slot] + 1;
+            kalman_update(M, slot, db);
+        }
+    }
+    // ---- births (sort.py:276-278): never-assigned detections ascending, then threshold-rejected ones ----
+    int nb = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int want = pass == 0 ? -1 : -2;
+        for (int base = 0; base < N; base += kWave) {
+            const int k = base + lane;
+            const bool f = (k < N) && (M.det_match[k] == want);
+            const unsigned long long mask = __ballot(f);
+            if (f) M.new_list[nb + __popcll(mask & lt)] = k;
+            nb += __popcll(mask);
+        }
+    }
+    if (T + nb > cap || nb > S.n_free) return kErrCapacity;
+    __syncthreads();
+    for (int k = lane; k < nb; k += kWave) {
+        const int slot = M.freel[S.n_free - 1 - k];
+        M.order[T + k] = slot;
+        float db[4];
+        dets.get(M.new_list[k], db);
+        track_init(M, slot, db);
+        M.gid[slot] = id_base + S.next_local + k;
+        M.tsu[slot] = 0;
+        M.streak[slot] = 0;
+        M.bframe[slot] = frame_global;
+        M.bk[slot] = k;
+    }
+    S.n_free -= nb;
+    S.next_local += nb;
+    const int T2 = T + nb;
+    __syncthreads();
+    // ---- emit newest first (sort.py:279-290) ----
+    int K = 0;
+    for (int top = T2; top > 0; top -= kWave) {
+        const int i = top - 1 - lane;
+        bool e = false;
+        double b[4] = {0., 0., 0., 0.}, conf = 0.;
+        int slot = 0;
+        if (i >= 0) {
+            slot = M.order[i];
+            if (M.tsu[slot] < 1 && (M.streak[slot] >= min_hits || S.frame_count <= min_hits)) {
+                x_to_bbox(M.kx[0 * cap + slot], M.kx[1 * cap + slot], M.kx[2 * cap + slot], M.kx[3 * cap + slot], b);
+                const double err = ((M.kP[0 * cap + slot] + M.kP[8 * cap + slot]) + M.kP[16 * cap + slot]) / 3.0;
+                conf = exp(-err * 0.1);
+                e = emit.accept(b, conf);
+            }
+        }
+        const unsigned long long mask = __ballot(e);
+        if (e) emit.write(K + __popcll(mask & lt), b, conf, M.gid[slot], M.bframe[slot], M.bk[slot]);
+        K += __popcll(mask);
+    }
+    // ---- reap (sort.py:291-293) ----
+    int Tn = 0;
+    for (int base = 0; base < T2; base += kWave) {
+        const int i = base + lane;
+        const bool act = i < T2;
+        int slot = 0;
+        bool live = false;
+        if (act) { slot = M.order[i]; live = !(M.tsu[slot] > max_age); }
+        const unsigned long long good = __ballot(act && live);
+        const unsigned long long bad = __ballot(act && !live);
+        if (act && live) M.order[Tn + __popcll(good & lt)] = slot;
+        if (act && !live) M.freel[S.n_free + __popcll(bad & lt)] = slot;
+        Tn += __popcll(good);
+        S.n_free += __popcll(bad);
+    }
+    S.n_tracks = Tn;
+    *n_births = nb;
+    *n_rows = K;
+    __syncthreads();
+    return 0;
+}
+
+
+}  // namespace wtdev

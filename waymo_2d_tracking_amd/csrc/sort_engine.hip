@@ -1,0 +1,486 @@
+// SORT engine on gfx950 (include/waymotrack.h, "SORT" section).
+//
+// Persistent kernel: grid = n_streams * n_classes wavefronts; wave (s, c) is the reference's
+// `Sort` object of class c inside the MultiClassTrackerSort of stream s (tracking/sort/tracker_sort.py:22-51,
+// tracking/utils.py:25-60) and iterates that stream's frames in-kernel.  Class trackers of a stream are
+// independent except for two global orders, both recovered afterwards without any serialisation:
+//   * track IDs  = running count of births in (stream, frame, class-first-seen, birth) order (sort.py:86,140),
+//   * output row order = (stream, frame, class-first-seen, newest track first)        (utils.py:31-58).
+// Each wave records births / emitted rows per (frame, class); `rank_classes_kernel` orders the classes of a
+// stream by first appearance, `scan_kernel` turns the per-(frame, class-rank) counts into offsets and
+// `finalize_kernel` scatters rows to their final position with their global id.
+#include "common.h"
+#include "sort_device.h"
+#include <vector>
+
+using namespace wtdev;
+
+namespace {
+
+constexpr int kLdsCostFloats = 8192;          // 32 KiB of cost matrix in LDS per wave
+constexpr size_t kLdsMunkresMax = 24 * 1024;  // stars/primes/covers
+
+struct Workspace {                       // device pointers carved from one block
+    // per tracker
+    double* kx; double* kP; double* pbox;
+    long long* gid;
+    int *tsu, *streak, *bframe, *bk, *order, *freel, *trk_match, *det_match, *new_list, *det_idx;
+    float* cost_g;
+    long long* first_key;                // per tracker: (frame << 32 | det position) of creation, or -1
+    // per (frame, class)
+    int* cnt;                            // emitted rows
+    int* births;                         // births
+    long long* ibase;                    // first intermediate slot of the (frame, class) block
+    // per intermediate slot
+    double* irow;                        // [5][n_dets]: x1, y1, w, h, score
+    int *ifr, *isc, *ij, *ibf, *ibk;
+    // ranked
+    int* rank;                           // [n_streams * C]: class rank inside its stream or -1
+    long long* rcnt;                     // [n_frames * C] ranked row counts -> exclusive scan
+    long long* rbirths;                  // [n_frames * C] ranked births     -> exclusive scan
+    double* thr_score; double* thr_iou;  // [C]
+    int* err;
+    long long* totals;                   // [2] rows, births
+    size_t bytes;
+};
+
+size_t munkres_lds_bytes(int capN, int cap) {
+    return wt::align_up((size_t)(2 * capN + cap) * sizeof(int) + (size_t)capN + (size_t)cap, 16);
+}
+
+Workspace carve_ws(void* base, int64_t n_dets, int64_t n_frames, int32_t n_streams, int C, int cap, int capN,
+                   bool need_cost_g) {
+    wt::Carver cv(base);
+    Workspace w;
+    const size_t nt = (size_t)n_streams * (size_t)C;
+    w.kx = cv.take<double>(nt * 7 * cap);
+    w.kP = cv.take<double>(nt * 49 * cap);
+    w.pbox = cv.take<double>(nt * 4 * cap);
+    w.gid = cv.take<long long>(nt * cap);
+    w.tsu = cv.take<int>(nt * cap);
+    w.streak = cv.take<int>(nt * cap);
+    w.bframe = cv.take<int>(nt * cap);
+    w.bk = cv.take<int>(nt * cap);
+    w.order = cv.take<int>(nt * cap);
+    w.freel = cv.take<int>(nt * cap);
+    w.trk_match = cv.take<int>(nt * cap);
+    w.det_match = cv.take<int>(nt * capN);
+    w.new_list = cv.take<int>(nt * capN);
+    w.det_idx = cv.take<int>(nt * capN);
+    w.cost_g = cv.take<float>(need_cost_g ? nt * (size_t)capN * cap : 1);
+    w.first_key = cv.take<long long>(nt);
+    w.cnt = cv.take<int>((size_t)n_frames * C);
+    w.births = cv.take<int>((size_t)n_frames * C);
+    w.ibase = cv.take<long long>((size_t)n_frames * C);
+    w.irow = cv.take<double>((size_t)n_dets * 5 + 1);
+    w.ifr = cv.take<int>((size_t)n_dets + 1);
+    w.isc = cv.take<int>((size_t)n_dets + 1);
+    w.ij = cv.take<int>((size_t)n_dets + 1);
+    w.ibf = cv.take<int>((size_t)n_dets + 1);
+    w.ibk = cv.take<int>((size_t)n_dets + 1);
+    w.rank = cv.take<int>(nt);
+    w.rcnt = cv.take<long long>((size_t)n_frames * C + 1);
+    w.rbirths = cv.take<long long>((size_t)n_frames * C + 1);
+    w.thr_score = cv.take<double>((size_t)C);
+    w.thr_iou = cv.take<double>((size_t)C);
+    w.err = cv.take<int>(4);
+    w.totals = cv.take<long long>(2);
+    w.bytes = cv.off;
+    return w;
+}
+
+__device__ __forceinline__ TrackerMem tracker_mem(const Workspace& w, size_t tk, int cap, int capN, bool cost_g) {
+    TrackerMem M;
+    M.kx = w.kx + tk * 7 * cap;
+    M.kP = w.kP + tk * 49 * cap;
+    M.pbox = w.pbox + tk * 4 * cap;
+    M.gid = w.gid + tk * cap;
+    M.tsu = w.tsu + tk * cap;
+    M.streak = w.streak + tk * cap;
+    M.bframe = w.bframe + tk * cap;
+    M.bk = w.bk + tk * cap;
+    M.order = w.order + tk * cap;
+    M.freel = w.freel + tk * cap;
+    M.trk_match = w.trk_match + tk * cap;
+    M.det_match = w.det_match + tk * capN;
+    M.new_list = w.new_list + tk * capN;
+    M.cost_g = cost_g ? w.cost_g + tk * (size_t)capN * cap : nullptr;
+    M.cap = cap;
+    M.capN = capN;
+    return M;
+}
+
+__device__ __forceinline__ MunkresMem munkres_mem(char* lds, int capN, int cap) {
+    MunkresMem L;
+    int* ip = reinterpret_cast<int*>(lds);
+    L.row_star = ip;
+    L.row_prime = ip + capN;
+    L.col_star = ip + 2 * capN;
+    L.row_cov = reinterpret_cast<unsigned char*>(ip + 2 * capN + cap);
+    L.col_cov = L.row_cov + capN;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched streams
+struct StreamDets {       // k-th detection of this class in the current frame -> float32 row (utils.py:33)
+    const double *x, *y, *w, *h;
+    const int* idx;
+    long long d0;
+    __device__ __forceinline__ void get(int k, float o[4]) const {
+        const long long d = d0 + idx[k];
+        const double xx = x[d], yy = y[d];
+        o[0] = (float)xx;
+        o[1] = (float)yy;
+        o[2] = (float)(xx + w[d]);
+        o[3] = (float)(yy + h[d]);
+    }
+};
+
+struct StreamEmit {       // utils.py:38-58 clip / drop / confidence clip, into the intermediate slots
+    double cw, ch;
+    double* irow;
+    int *ifr, *isc, *ij, *ibf, *ibk;
+    long long n_slots, base;
+    int f, sc;
+    __device__ __forceinline__ static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+    __device__ __forceinline__ bool accept(double b[4], double& conf) const {
+        if (cw > 0) {
+            b[0] = clipd(b[0], 0, cw); b[1] = clipd(b[1], 0, ch);
+            b[2] = clipd(b[2], 0, cw); b[3] = clipd(b[3], 0, ch);
+            if ((b[2] - b[0]) < 1 || (b[3] - b[1]) < 1) return false;
+            conf = clipd(conf, 0.2, 1.0);
+        }
+        return true;
+    }
+    __device__ __forceinline__ void write(int j, const double b[4], double conf, long long, int bframe, int bk) const {
+        const long long p = base + j;
+        irow[p] = b[0];
+        irow[n_slots + p] = b[1];
+        irow[2 * n_slots + p] = b[2] - b[0];
+        irow[3 * n_slots + p] = b[3] - b[1];
+        irow[4 * n_slots + p] = conf;
+        ifr[p] = f; isc[p] = sc; ij[p] = j; ibf[p] = bframe; ibk[p] = bk;
+    }
+};
+
+__global__ __launch_bounds__(kWave) void sort_streams_kernel(
+    const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
+    const double* __restrict__ h, const double* __restrict__ score, const int32_t* __restrict__ category,
+    const int64_t* __restrict__ frame_det_offsets, const int64_t* __restrict__ stream_frame_offsets,
+    const double* __restrict__ clip_w, const double* __restrict__ clip_h, int C, int max_age, int min_hits,
+    int cap, int capN, int lds_cost_cap, bool have_cost_g, long long n_slots, Workspace ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = lanemask_lt();
+    const size_t tk = blockIdx.x;
+    const int s = (int)(tk / C);
+    const int c = (int)(tk % C) + 1;
+    float* lds_cost = reinterpret_cast<float*>(smem);
+    MunkresMem L = munkres_mem(smem + (size_t)lds_cost_cap * sizeof(float), capN, cap);
+    TrackerMem M = tracker_mem(ws, tk, cap, capN, have_cost_g);
+    int* det_idx = ws.det_idx + tk * capN;
+    for (int i = lane; i < cap; i += kWave) M.freel[i] = cap - 1 - i;
+    TrackerState S = {0, cap, 0, 0};
+    __syncthreads();
+    const double thr_iou = ws.thr_iou[c - 1];
+    const double cw = clip_w ? clip_w[s] : 0.0, ch = clip_h ? clip_h[s] : 0.0;
+    bool created = false;
+    long long first_key = -1;
+    const long long f0 = stream_frame_offsets[s], f1 = stream_frame_offsets[s + 1];
+    for (long long f = f0; f < f1; ++f) {
+        const long long d0 = frame_det_offsets[f], d1 = frame_det_offsets[f + 1];
+        // select this class's detections (utils.py:79,86 filters; tracker_sort.py:29-37 bucketing) and count the
+        // valid detections of lower class ids: they own the intermediate slots in front of ours
+        int N = 0, lower = 0, first_pos = -1;
+        bool overflow = false;
+        for (long long base = d0; base < d1; base += kWave) {
+            const long long d = base + lane;
+            bool mine = false, low = false;
+            if (d < d1) {
+                const int cat = category[d];
+                const bool valid = (cat >= 1 && cat <= C) && !(w[d] < 1) && !(h[d] < 1) && !(score[d] < ws.thr_score[cat - 1]);
+                mine = valid && cat == c;
+                low = valid && cat < c;
+            }
+            const unsigned long long mm = __ballot(mine);
+            if (mine) {
+                const int k = N + __popcll(mm & lt);
+                if (k < capN) det_idx[k] = (int)(d - d0);
+            }
+            if (mm && first_pos < 0) first_pos = (int)(base - d0) + __builtin_ctzll(mm);
+            N += __popcll(mm);
+            lower += __popcll(__ballot(low));
+        }
+        if (N > capN) overflow = true;
+        if (!created) {
+            if (N == 0) continue;
+            created = true;
+            first_key = ((f - f0) << 32) | (long long)first_pos;
+        }
+        __syncthreads();
+        StreamDets dets = {x, y, w, h, det_idx, d0};
+        StreamEmit emit = {cw, ch, ws.irow, ws.ifr, ws.isc, ws.ij, ws.ibf, ws.ibk, n_slots, d0 + lower, (int)f, (int)tk};
+        int nb = 0, nr = 0;
+        int rc = overflow ? WT_ERR_CAPACITY
+                          : tracker_step(M, S, L, lds_cost, lds_cost_cap, dets, N, thr_iou, max_age, min_hits, (int)f,
+                                         0ll, emit, &nb, &nr);
+        if (rc) {
+            if (lane == 0) atomicMax(ws.err, rc);
+            break;
+        }
+        if (lane == 0) { ws.cnt[f * C + c - 1] = nr; ws.births[f * C + c - 1] = nb; }
+    }
+    if (lane == 0) ws.first_key[tk] = created ? first_key : -1;
+}
+
+// class rank inside its stream = order of first appearance (dict insertion order, tracker_sort.py:32-33,41)
+__global__ void rank_classes_kernel(int n_streams, int C, Workspace ws) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    for (int c = 0; c < C; ++c) {
+        const long long k = ws.first_key[(size_t)s * C + c];
+        int r = -1;
+        if (k >= 0) {
+            r = 0;
+            for (int o = 0; o < C; ++o) {
+                const long long ko = ws.first_key[(size_t)s * C + o];
+                if (o != c && ko >= 0 && ko < k) ++r;
+            }
+        }
+        ws.rank[(size_t)s * C + c] = r;
+    }
+}
+
+// ranked per-(frame, class-rank) counts
+__global__ void gather_ranked_kernel(long long n_frames, int n_streams, int C,
+                                     const int64_t* __restrict__ stream_frame_offsets, Workspace ws) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_frames * C) return;
+    const long long f = e / C;
+    const int c = (int)(e - f * C);
+    int lo = 0, hi = n_streams;                    // stream of frame f: last s with offsets[s] <= f
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (stream_frame_offsets[mid] <= f) lo = mid; else hi = mid;
+    }
+    const int r = ws.rank[(size_t)lo * C + c];
+    if (r >= 0) {
+        ws.rcnt[f * C + r] = ws.cnt[e];
+        ws.rbirths[f * C + r] = ws.births[e];
+    }
+}
+
+// single-block exclusive scan of two int64 arrays (n <= a few million: launch-latency sized)
+__global__ __launch_bounds__(1024) void scan2_kernel(long long n, long long* a, long long* b, long long* totals) {
+    __shared__ long long sa[1024], sb[1024];
+    const int t = threadIdx.x;
+    const long long chunk = (n + 1023) / 1024;
+    const long long lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    long long xa = 0, xb = 0;
+    for (long long i = lo; i < hi; ++i) { xa += a[i]; xb += b[i]; }
+    sa[t] = xa; sb[t] = xb;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        long long va = 0, vb = 0;
+        if (t >= o) { va = sa[t - o]; vb = sb[t - o]; }
+        __syncthreads();
+        sa[t] += va; sb[t] += vb;
+        __syncthreads();
+    }
+    long long ra = sa[t] - xa, rb = sb[t] - xb;      // exclusive prefix of this thread's chunk
+    for (long long i = lo; i < hi; ++i) {
+        const long long va = a[i], vb = b[i];
+        a[i] = ra; b[i] = rb;
+        ra += va; rb += vb;
+    }
+    if (t == 1023) { totals[0] = sa[1023]; totals[1] = sb[1023]; }
+}
+
+__global__ void finalize_kernel(long long n_slots, int C, long long id_base, Workspace ws,
+                                int64_t* __restrict__ out_frame, int32_t* __restrict__ out_category,
+                                double* __restrict__ out_bbox4, double* __restrict__ out_score,
+                                int64_t* __restrict__ out_object_id) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_slots) return;
+    const int f = ws.ifr[p];
+    if (f < 0) return;
+    const int sc = ws.isc[p];
+    const int r = ws.rank[sc];
+    const long long dst = ws.rcnt[(long long)f * C + r] + ws.ij[p];
+    out_frame[dst] = f;
+    out_category[dst] = sc % C + 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out_bbox4[4 * dst + q] = ws.irow[q * n_slots + p];
+    out_score[dst] = ws.irow[4 * n_slots + p];
+    // sort.py:141 id = count++ ; :288 emits id + 1
+    out_object_id[dst] = id_base + ws.rbirths[(long long)ws.ibf[p] * C + r] + ws.ibk[p] + 1;
+}
+
+__global__ void totals_kernel(const long long* totals, const int* err, int64_t* n_out, int64_t* n_births) {
+    n_out[0] = err[0] ? -(int64_t)err[0] : totals[0];
+    n_births[0] = totals[1];
+}
+
+int pick_caps(int64_t max_frame_dets, const wt_track_params* p, int* cap, int* capN, int* lds_cost, bool* cost_g,
+              size_t* lds_bytes) {
+    if (!p || p->n_classes < 1 || !p->iou_threshold || !p->score_threshold || p->max_age < 0) {
+        wt::set_error("bad wt_track_params");
+        return WT_ERR_INVALID;
+    }
+    const int64_t n = max_frame_dets > 0 ? max_frame_dets : 1;
+    const int64_t c = n * ((int64_t)p->max_age + 2);
+    if (c > (1 << 20)) { wt::set_error("per-tracker capacity too large (%lld tracks)", (long long)c); return WT_ERR_CAPACITY; }
+    *capN = (int)n;
+    *cap = (int)c;
+    const int64_t full = (int64_t)(*capN) * (*cap);
+    *lds_cost = (int)(full < kLdsCostFloats ? full : kLdsCostFloats);
+    *cost_g = full > kLdsCostFloats;
+    const size_t mk = munkres_lds_bytes(*capN, *cap);
+    if (mk > kLdsMunkresMax) { wt::set_error("frame with %lld detections exceeds the LDS budget of the assignment kernel", (long long)n); return WT_ERR_CAPACITY; }
+    *lds_bytes = (size_t)(*lds_cost) * sizeof(float) + mk;
+    return WT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t wt_track_streams_workspace(int64_t n_dets, int64_t n_frames, int32_t n_streams, int64_t max_frame_dets,
+                                  const wt_track_params* params) {
+    int cap, capN, lds_cost; bool cost_g; size_t lds;
+    if (pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds) != WT_OK) return 0;
+    return carve_ws(nullptr, n_dets, n_frames, n_streams, params->n_classes, cap, capN, cost_g).bytes + 256;
+}
+
+int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
+                         const double* score, const int32_t* category,
+                         int64_t n_frames, const int64_t* frame_det_offsets,
+                         int32_t n_streams, const int64_t* stream_frame_offsets,
+                         const double* clip_w, const double* clip_h, int64_t max_frame_dets,
+                         const wt_track_params* params, int64_t id_base,
+                         int64_t* out_frame, int32_t* out_category, double* out_bbox4, double* out_score,
+                         int64_t* out_object_id, int64_t* n_out_dev, int64_t* n_births_dev,
+                         void* workspace, size_t workspace_bytes, void* stream_) {
+    WT_TRY(wt::ensure_device());
+    hipStream_t stream = (hipStream_t)stream_;
+    int cap, capN, lds_cost; bool cost_g; size_t lds;
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    const int C = params->n_classes;
+    if (n_streams <= 0 || n_frames <= 0) {
+        WT_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), stream));
+        WT_HIP(hipMemsetAsync(n_births_dev, 0, sizeof(int64_t), stream));
+        return WT_OK;
+    }
+    const uintptr_t mis = (uintptr_t)workspace & 255;
+    char* base = (char*)workspace + (mis ? 256 - mis : 0);
+    Workspace ws = carve_ws(base, n_dets, n_frames, n_streams, C, cap, capN, cost_g);
+    if (!workspace || workspace_bytes < ws.bytes + 256) {
+        wt::set_error("tracking workspace too small: need %zu bytes, have %zu", ws.bytes + 256, workspace_bytes);
+        return WT_ERR_CAPACITY;
+    }
+    WT_HIP(hipMemcpyAsync(ws.thr_score, params->score_threshold, sizeof(double) * C, hipMemcpyHostToDevice, stream));
+    WT_HIP(hipMemcpyAsync(ws.thr_iou, params->iou_threshold, sizeof(double) * C, hipMemcpyHostToDevice, stream));
+    WT_HIP(hipMemsetAsync(ws.err, 0, sizeof(int) * 4, stream));
+    WT_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * (size_t)n_frames * C, stream));
+    WT_HIP(hipMemsetAsync(ws.births, 0, sizeof(int) * (size_t)n_frames * C, stream));
+    WT_HIP(hipMemsetAsync(ws.ifr, 0xFF, sizeof(int) * ((size_t)n_dets + 1), stream));
+    WT_HIP(hipMemsetAsync(ws.rcnt, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
+    WT_HIP(hipMemsetAsync(ws.rbirths, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
+    const unsigned n_trackers = (unsigned)n_streams * (unsigned)C;
+    hipLaunchKernelGGL(sort_streams_kernel, dim3(n_trackers), dim3(kWave), lds, stream, x, y, w, h, score, category,
+                       frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
+                       (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws);
+    WT_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rank_classes_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, (int)n_streams, C, ws);
+    const long long ne = (long long)n_frames * C;
+    hipLaunchKernelGGL(gather_ranked_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream,
+                       (long long)n_frames, (int)n_streams, C, stream_frame_offsets, ws);
+    hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(1024), 0, stream, ne, ws.rcnt, ws.rbirths, ws.totals);
+    if (n_dets > 0)
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_dets + 255) / 256)), dim3(256), 0, stream,
+                           (long long)n_dets, C, (long long)id_base, ws, out_frame, out_category, out_bbox4, out_score,
+                           out_object_id);
+    hipLaunchKernelGGL(totals_kernel, dim3(1), dim3(1), 0, stream, (const long long*)ws.totals, ws.err, n_out_dev,
+                       n_births_dev);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+int wt_track_streams_host(int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
+                          const double* score, const int32_t* category,
+                          int64_t n_frames, const int64_t* frame_det_offsets,
+                          int32_t n_streams, const int64_t* stream_frame_offsets,
+                          const double* clip_w, const double* clip_h,
+                          const wt_track_params* params, int64_t id_base,
+                          int64_t* out_frame, int32_t* out_category, double* out_bbox4, double* out_score,
+                          int64_t* out_object_id, int64_t* n_out, int64_t* n_births) {
+    WT_TRY(wt::ensure_device());
+    *n_out = 0;
+    *n_births = 0;
+    if (n_streams <= 0 || n_frames <= 0) return WT_OK;
+    if (!params) { wt::set_error("params is NULL"); return WT_ERR_INVALID; }
+    int64_t max_frame = 0;
+    for (int64_t f = 0; f < n_frames; ++f) {
+        const int64_t c = frame_det_offsets[f + 1] - frame_det_offsets[f];
+        if (c < 0) { wt::set_error("frame_det_offsets must be non-decreasing"); return WT_ERR_INVALID; }
+        if (c > max_frame) max_frame = c;
+    }
+    if (frame_det_offsets[n_frames] != n_dets || stream_frame_offsets[n_streams] != n_frames) {
+        wt::set_error("CSR offsets do not cover n_dets / n_frames");
+        return WT_ERR_INVALID;
+    }
+    for (int64_t i = 0; i < n_dets; ++i)
+        if (category[i] < 1 || category[i] > params->n_classes) {
+            wt::set_error("category %d outside 1..%d", (int)category[i], (int)params->n_classes);
+            return WT_ERR_INVALID;
+        }
+    const size_t nd = (size_t)n_dets;
+    wt::DevBuf dx, dy, dw, dh, ds, dc, dfo, dso, dcw, dch, of, oc, ob, os, oi, dn, dws;
+    WT_TRY(dx.alloc(8 * nd)); WT_TRY(dy.alloc(8 * nd)); WT_TRY(dw.alloc(8 * nd)); WT_TRY(dh.alloc(8 * nd));
+    WT_TRY(ds.alloc(8 * nd)); WT_TRY(dc.alloc(4 * nd));
+    WT_TRY(dfo.alloc(8 * (size_t)(n_frames + 1))); WT_TRY(dso.alloc(8 * (size_t)(n_streams + 1)));
+    WT_TRY(dcw.alloc(8 * (size_t)n_streams)); WT_TRY(dch.alloc(8 * (size_t)n_streams));
+    WT_TRY(of.alloc(8 * (nd + 1))); WT_TRY(oc.alloc(4 * (nd + 1))); WT_TRY(ob.alloc(32 * (nd + 1)));
+    WT_TRY(os.alloc(8 * (nd + 1))); WT_TRY(oi.alloc(8 * (nd + 1))); WT_TRY(dn.alloc(16));
+    if (nd) {
+        WT_HIP(hipMemcpy(dx.p, x, 8 * nd, hipMemcpyHostToDevice)); WT_HIP(hipMemcpy(dy.p, y, 8 * nd, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(dw.p, w, 8 * nd, hipMemcpyHostToDevice)); WT_HIP(hipMemcpy(dh.p, h, 8 * nd, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(ds.p, score, 8 * nd, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(dc.p, category, 4 * nd, hipMemcpyHostToDevice));
+    }
+    WT_HIP(hipMemcpy(dfo.p, frame_det_offsets, 8 * (size_t)(n_frames + 1), hipMemcpyHostToDevice));
+    WT_HIP(hipMemcpy(dso.p, stream_frame_offsets, 8 * (size_t)(n_streams + 1), hipMemcpyHostToDevice));
+    std::vector<double> zeros;
+    if (!clip_w || !clip_h) zeros.assign((size_t)n_streams, 0.0);
+    WT_HIP(hipMemcpy(dcw.p, clip_w ? clip_w : zeros.data(), 8 * (size_t)n_streams, hipMemcpyHostToDevice));
+    WT_HIP(hipMemcpy(dch.p, clip_h ? clip_h : zeros.data(), 8 * (size_t)n_streams, hipMemcpyHostToDevice));
+    const size_t wsb = wt_track_streams_workspace(n_dets, n_frames, n_streams, max_frame, params);
+    if (!wsb) return WT_ERR_CAPACITY;
+    WT_TRY(dws.alloc(wsb));
+    WT_TRY(wt_track_streams_dev(n_dets, dx.as<double>(), dy.as<double>(), dw.as<double>(), dh.as<double>(),
+                                ds.as<double>(), dc.as<int32_t>(), n_frames, dfo.as<int64_t>(), n_streams,
+                                dso.as<int64_t>(), dcw.as<double>(), dch.as<double>(), max_frame, params, id_base,
+                                of.as<int64_t>(), oc.as<int32_t>(), ob.as<double>(), os.as<double>(), oi.as<int64_t>(),
+                                dn.as<int64_t>(), dn.as<int64_t>() + 1, dws.p, wsb, nullptr));
+    WT_HIP(hipDeviceSynchronize());
+    int64_t res[2] = {0, 0};
+    WT_HIP(hipMemcpy(res, dn.p, 16, hipMemcpyDeviceToHost));
+    if (res[0] < 0) {
+        wt::set_error("SORT kernel reported status %lld (4 = capacity, 5 = assignment did not converge)", (long long)-res[0]);
+        return (int)-res[0];
+    }
+    *n_out = res[0];
+    *n_births = res[1];
+    const size_t k = (size_t)res[0];
+    if (k) {
+        WT_HIP(hipMemcpy(out_frame, of.p, 8 * k, hipMemcpyDeviceToHost));
+        WT_HIP(hipMemcpy(out_category, oc.p, 4 * k, hipMemcpyDeviceToHost));
+        WT_HIP(hipMemcpy(out_bbox4, ob.p, 32 * k, hipMemcpyDeviceToHost));
+        WT_HIP(hipMemcpy(out_score, os.p, 8 * k, hipMemcpyDeviceToHost));
+        WT_HIP(hipMemcpy(out_object_id, oi.p, 8 * k, hipMemcpyDeviceToHost));
+    }
+    return WT_OK;
+}
+
+}  // extern "C"

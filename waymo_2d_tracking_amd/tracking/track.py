@@ -1,0 +1,55 @@
+"""Drop-in for /root/reference/tracking/track.py (same flags, same prints, same output JSON):
+
+    python -m waymo_2d_tracking_amd.tracking.track --input det.json --output tracks.json \
+        --max-age=2 --min-hits=0 --score-threshold=0.95,0.6,1.0,0.9
+
+All (segment, camera) streams are tracked in one GPU call (utils.track_all) instead of the sequential loop of
+track.py:43-47; `--ground-truth` is accepted but, like in the reference, its content is never used (the file
+is not required to exist).
+"""
+import argparse
+import json
+import time
+
+from .utils import read_data_file, track_all
+
+
+def _floats(s):
+    return [float(item) for item in s.split(',')]
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--ground-truth", type=str, default='/data/waymo/det2d/validation/images.json',
+                        help='ground-truth json')
+    parser.add_argument("--input", type=str, default='submission_12545.json', help='submission.json')
+    parser.add_argument("--output", type=str, default='tracker_predictions.json',
+                        help='file to save the tracker predictions')
+    parser.add_argument("--max-age", type=int, default=1, help='SORT max-age')
+    parser.add_argument("--min-hits", type=int, default=0, help='SORT min-hits')
+    parser.add_argument("--score-threshold", type=_floats, default=[0.95, 0.6, 1.0, 0.9],
+                        help='score threshold to track')
+    parser.add_argument("--iou-threshold", type=_floats, default=[0.01, 0.01, 1.0, 0.0],
+                        help='IOU threshold for tracking')
+    parser.add_argument("--segment-id", type=str, help='track only a single segment')
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    print(args)
+    predictions = read_data_file(args.input, args.score_threshold)
+    if args.segment_id:
+        predictions = {k: v for k, v in predictions.items() if k in [args.segment_id]}
+    start_time = time.time()
+    for segment_id in predictions.keys():
+        print(segment_id)
+    tracked_predictions = track_all(predictions, args.iou_threshold, args.max_age, args.min_hits)
+    print("duration: %.2fs" % (time.time() - start_time))
+    with open(args.output, 'wt') as fp:
+        json.dump(tracked_predictions, fp)
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())
