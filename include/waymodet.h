@@ -1,0 +1,67 @@
+/* libwaymotrack - detector custom ops (C ABI) of the Cascade R-CNN X152-FPN hot path.
+ *
+ * The reference reaches these operators through detectron2 0.1.3 / torchvision 0.6 (not vendored):
+ *   detnet/nn/detectron2_det/__init__.py:56,116 builds and calls the detectron2 GeneralizedRCNN whose layers
+ *   (printed in logs/12442/job.log:336-1221) contain ROIAlign (job.log:1138-1143), DeformConv (job.log:412-415),
+ *   the cascade box heads (job.log:1146-1218) and torchvision.ops.nms (box_utils.py:3 imports the same op).
+ * Semantics are restated in SURVEY.md App. C ("parity unpinned": detectron2 cannot be imported in the build
+ * container; the ops are checked against a float64/float32 PyTorch restatement in tests/test_gpu_detops.py).
+ *
+ * All pointers are DEVICE pointers; `stream` is a hipStream_t passed as void*; calls are stream-ordered and never
+ * synchronise.  Feature maps are NHWC float32 ("channels_last" storage of an (N,C,H,W) torch tensor).
+ * Status codes and wt_last_error() as in waymotrack.h.
+ */
+#ifndef WAYMODET_H
+#define WAYMODET_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ROIPooler = level assignment + ROIAlign(output 7x7 (pooled), spatial_scale 1/stride, sampling_ratio 0, aligned=True)
+ * over up to 4 FPN levels in one launch (detectron2 ROIPooler; job.log:1137-1143).
+ *   feats      : HOST array of n_levels DEVICE pointers; feats[l] = (N, H_l, W_l, C) NHWC float32;
+ *                heights / widths / scales: HOST arrays, scales[l] = 1/stride_l
+ *   rois       : (R, 5) float32 [batch_index, x1, y1, x2, y2] in image coordinates
+ *   level assignment: floor(canonical_level + log2(sqrt(area)/canonical_size + 1e-8)) clamped to
+ *                     [min_level, min_level + n_levels - 1]   (detectron2 assign_boxes_to_levels)
+ *   out        : (R, pooled, pooled, C) NHWC float32 */
+int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* heights, const int32_t* widths,
+                        const float* scales, int n_levels, int channels, int batch,
+                        const float* rois, int n_rois, int pooled, int min_level, int canonical_level,
+                        float canonical_size, float* out, void* stream);
+
+/* torchvision.ops.nms / detectron2 batched_nms restated: boxes (n,4) xyxy float32 ALREADY sorted by descending
+ * score, idxs (n) int32 group id (NULL = one group); box j is suppressed by a kept box i < j of the same group
+ * when IoU(i,j) > iou_threshold.  keep_mask (n) uint8 receives 1 for kept boxes; n_keep (device int32) their count.
+ * workspace: wd_nms_workspace(n) bytes. */
+size_t wd_nms_workspace(int n);
+int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_threshold,
+                      uint8_t* keep_mask, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* detectron2 DeformConv / ModulatedDeformConv forward (job.log:412-415), kernel 3x3, dilation 1,
+ * deformable_groups 1:
+ *   x      : (N, H, W, C_in) NHWC float32
+ *   offset : (N, H_out, W_out, 18) NHWC float32, channel 2k = dy, 2k+1 = dx of tap k = kh*3+kw
+ *   mask   : (N, H_out, W_out, 9) or NULL (non-modulated)
+ *   weight : packed by wd_deform_pack_weight from the (C_out, C_in/groups, 3, 3) OIHW tensor
+ *   scale/bias (C_out) or NULL: fused per-channel affine (FrozenBatchNorm2d) ; relu != 0 fuses ReLU
+ *   y      : (N, H_out, W_out, C_out) NHWC float32,  H_out = (H + 2*pad - 3)/stride + 1 */
+size_t wd_deform_packed_weight_floats(int c_in, int c_out, int groups);
+int wd_deform_pack_weight(const float* weight_oihw, int c_in, int c_out, int groups, float* packed, void* stream);
+int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
+                          const float* scale, const float* bias, int relu,
+                          int batch, int h, int w, int c_in, int c_out, int groups, int stride, int pad,
+                          float* y, void* stream);
+
+/* Box-head FC / 1x1 convolution as GEMM on f32-input MFMA:  C = act(A (M,K) * B^T + bias [+ residual])
+ *   A row-major (M,K) float32; Bt row-major (N,K) float32 (a torch Linear / 1x1-conv weight as stored);
+ *   bias (N) or NULL; residual (M,N) or NULL; relu != 0 fuses ReLU; C row-major (M,N). */
+int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias, const float* residual, int relu,
+                   int M, int N, int K, float* C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -27,6 +27,31 @@ class TrackParams(C.Structure):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and loads
+    it by file name; if libwaymotrack.so pulled /opt/rocm's copy first, a later ``import torch`` would load a second
+    runtime and neither would see the other's devices/streams.  Loading torch's copy first (without importing
+    torch) makes both resolve to the same library whatever the import order."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib():
     """Load the HIP library (once).  Raises WaymoTrackError if it has not been built."""
     global _lib
@@ -35,6 +60,7 @@ def lib():
             raise WaymoTrackError(
                 '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+        _preload_torch_hip_runtime()
         _lib = C.CDLL(LIB_PATH)
         _lib.wt_last_error.restype = C.c_char_p
         _lib.wt_idctr_create.restype = C.c_void_p

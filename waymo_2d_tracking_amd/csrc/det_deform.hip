@@ -1,0 +1,204 @@
+// Deformable 3x3 convolution forward (detectron2 DeformConv / ModulatedDeformConv; logs/12442/job.log:412-415,
+// SURVEY.md App. C) as an implicit GEMM on the gfx950 f32 matrix cores, NHWC, groups = 32, deformable_groups = 1.
+//
+// Workgroup = 64 output pixels x 128 channels (= 128/Cg whole groups), 256 threads:
+//   1. sampling table in LDS: for each (pixel, tap) the 4 bilinear corner pixels and weights (x mask); the table is
+//      shared by every channel because deformable_groups = 1;
+//   2. per tap: the 64 x 128 im2col slab is gathered with 512-byte coalesced runs (32 lanes x float4 = 128 channels
+//      of one corner pixel), blended, and staged in LDS (row stride 130 floats: conflict-free ds_read_b32 for the
+//      MFMA A fragments, 8-byte aligned rows for the ds_write_b64 staging);
+//   3. each wave multiplies the slab with its 32 output channels' weights: v_mfma_f32_16x16x4_f32, A from LDS,
+//      B (packed [group][tap][ci][co]) straight from L2, 4 x 2 accumulator tiles per wave;
+//   4. epilogue fuses the FrozenBatchNorm affine and ReLU and writes NHWC.
+// Per layer: 2*C_out*(C_in/groups)*9*H_out*W_out flops (5.66 GFLOP for every res3/res4/res5 layer at 1920x1280).
+#include "common.h"
+#include "../../include/waymodet.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int TP = 64;          // pixels per workgroup
+constexpr int CCH = 128;        // channels per workgroup
+constexpr int LDC = CCH + 2;    // LDS row stride of the im2col slab
+
+struct Sample {
+    int idx[4];     // input pixel index (h*W + w) of the 4 corners, -1 = outside
+    float wgt[4];
+};
+
+template <int CG>
+__global__ __launch_bounds__(256) void deform_conv3x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
+    const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ bias, int relu,
+    int batch, int H, int W, int C, int Cout, int Ho, int Wo, int stride, int pad, float* __restrict__ y) {
+    __shared__ Sample tab[TP * 9];
+    __shared__ __attribute__((aligned(16))) float col[TP * LDC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long npix = (long)batch * Ho * Wo;
+    const long p0 = (long)blockIdx.x * TP;
+    const int c0 = blockIdx.y * CCH;             // first input (= output) channel of this chunk
+    // ---- 1. sampling table ----
+    for (int e = tid; e < TP * 9; e += 256) {
+        const int p = e / 9, k = e - 9 * p;
+        const long gp = p0 + p;
+        Sample s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s.idx[q] = -1; s.wgt[q] = 0.f; }
+        if (gp < npix) {
+            const int n = (int)(gp / ((long)Ho * Wo));
+            const int rem = (int)(gp - (long)n * Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            const int kh = k / 3, kw = k - 3 * kh;
+            const float* off = offset + (size_t)gp * 18;
+            const float h_im = (float)(ho * stride - pad + kh) + off[2 * k];
+            const float w_im = (float)(wo * stride - pad + kw) + off[2 * k + 1];
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                const int hh = hl + 1, wh = wl + 1;
+                const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                const float uh = 1.f - lh, uw = 1.f - lw;
+                const float m = mask ? mask[(size_t)gp * 9 + k] : 1.f;
+                const int base = n * H * W;
+                if (hl >= 0 && wl >= 0) { s.idx[0] = base + hl * W + wl; s.wgt[0] = uh * uw * m; }
+                if (hl >= 0 && wh <= W - 1) { s.idx[1] = base + hl * W + wh; s.wgt[1] = uh * lw * m; }
+                if (hh <= H - 1 && wl >= 0) { s.idx[2] = base + hh * W + wl; s.wgt[2] = lh * uw * m; }
+                if (hh <= H - 1 && wh <= W - 1) { s.idx[3] = base + hh * W + wh; s.wgt[3] = lh * lw * m; }
+            }
+        }
+        tab[e] = s;
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int gq = tid & 31;           // float4 column of the slab this thread gathers
+    const int gp0 = tid >> 5;          // first pixel row (rows gp0, gp0 + 8, ...)
+    const int co_w = wave * 32;        // this wave's 32 output channels inside the chunk
+    for (int k = 0; k < 9; ++k) {
+        // ---- 2. gather + blend the tap's im2col slab ----
+#pragma unroll
+        for (int i = 0; i < TP / 8; ++i) {
+            const int p = gp0 + 8 * i;
+            const Sample s = tab[p * 9 + k];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (s.idx[q] >= 0) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
+                    v.x += s.wgt[q] * t.x; v.y += s.wgt[q] * t.y; v.z += s.wgt[q] * t.z; v.w += s.wgt[q] * t.w;
+                }
+            }
+            float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+        // ---- 3. MFMA: out[64 px][32 co of this wave] += slab[64 px][ci of the group] * W[ci][co] ----
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co_l = co_w + 16 * nt;                 // first co of this N tile inside the chunk
+            const int g_l = co_l / CG;                       // group inside the chunk
+            const int g = (c0 + co_l) / CG;                  // global group
+            const int co_g = (co_l % CG) + (lane & 15);      // co inside the group
+            const float* wb = wp + ((size_t)(g * 9 + k) * CG) * CG + co_g;
+#pragma unroll
+            for (int kk = 0; kk < CG / 4; ++kk) {
+                const int ci = kk * 4 + (lane >> 4);
+                const float b = wb[(size_t)ci * CG];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float a = col[(mt * 16 + (lane & 15)) * LDC + g_l * CG + ci];
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- 4. epilogue ----
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = c0 + co_w + 16 * nt + (lane & 15);
+        const float sc = scale ? scale[co] : 1.f;
+        const float bi = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long gp = p0 + mt * 16 + (lane >> 4) * 4 + r;
+                if (gp < npix) {
+                    float v = acc[mt][nt][r] * sc + bi;
+                    if (relu) v = fmaxf(v, 0.f);
+                    y[(size_t)gp * Cout + co] = v;
+                }
+            }
+    }
+}
+
+// (C_out, C_in/groups, 3, 3) OIHW -> [group][tap][ci][co]
+__global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout, float* __restrict__ packed) {
+    const long total = (long)cout * cg * 9;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        // e indexes packed: ((g*9 + k)*cg + ci)*cg + co
+        const int co = (int)(e % cg);
+        const int ci = (int)((e / cg) % cg);
+        const int k = (int)((e / ((long)cg * cg)) % 9);
+        const int g = (int)(e / ((long)cg * cg * 9));
+        packed[e] = w[(((size_t)(g * cg + co) * cg) + ci) * 9 + k];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t wd_deform_packed_weight_floats(int c_in, int c_out, int groups) {
+    if (groups <= 0 || c_in % groups || c_in != c_out) return 0;
+    return (size_t)c_out * (size_t)(c_in / groups) * 9;
+}
+
+int wd_deform_pack_weight(const float* weight_oihw, int c_in, int c_out, int groups, float* packed, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (!wd_deform_packed_weight_floats(c_in, c_out, groups)) {
+        wt::set_error("wd_deform_pack_weight: needs c_in == c_out divisible by groups");
+        return WT_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, weight_oihw, c_in / groups, c_out, packed);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
+                          const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
+                          int c_out, int groups, int stride, int pad, float* y, void* stream_) {
+    WT_TRY(wt::ensure_device());
+    if (c_in != c_out || groups <= 0 || c_in % groups || c_in % CCH || stride < 1 || batch < 1 || h < 1 || w < 1 ||
+        ((uintptr_t)x & 15)) {
+        wt::set_error("wd_deform_conv3x3_f32: unsupported shape (c_in=%d c_out=%d groups=%d; need c_in == c_out, c_in %% 128 == 0)",
+                      c_in, c_out, groups);
+        return WT_ERR_INVALID;
+    }
+    const int cg = c_in / groups;
+    const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
+    if (ho < 1 || wo < 1) return WT_OK;
+    const long npix = (long)batch * ho * wo;
+    dim3 grid((unsigned)((npix + TP - 1) / TP), (unsigned)(c_in / CCH));
+    hipStream_t stream = (hipStream_t)stream_;
+#define WD_LAUNCH(CG)                                                                                              \
+    hipLaunchKernelGGL(deform_conv3x3_kernel<CG>, grid, dim3(256), 0, stream, x, offset, mask, packed_weight, scale, \
+                       bias, relu, batch, h, w, c_in, c_out, ho, wo, stride, pad, y)
+    if (cg == 16) WD_LAUNCH(16);
+    else if (cg == 32) WD_LAUNCH(32);
+    else if (cg == 64) WD_LAUNCH(64);
+    else {
+        wt::set_error("wd_deform_conv3x3_f32: channels per group must be 16, 32 or 64 (got %d)", cg);
+        return WT_ERR_INVALID;
+    }
+#undef WD_LAUNCH
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""Detector custom ops: torch-tensor front-ends of the HIP kernels declared in include/waymodet.h.
+
+torch is plumbing here (device memory + current stream); every function enqueues a hand-written gfx950 kernel
+of libwaymotrack.so on the current stream and raises if the library or a GPU is missing (no fallback).
+Feature maps are (N, C, H, W) tensors in ``torch.channels_last`` storage, i.e. NHWC in memory.
+"""
+import ctypes as C
+
+import torch
+
+from ... import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _nhwc(x):
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+
+def roi_pool_fpn(feats, rois, scales, pooled=7, min_level=2, canonical_level=4, canonical_size=224.0):
+    """detectron2 ROIPooler (ROIAlign aligned=True, sampling_ratio=0) over FPN levels.
+    feats: list of (N,C,H_l,W_l); rois (R,5) [batch,x1,y1,x2,y2] -> (R,C,pooled,pooled) channels_last."""
+    feats = [_nhwc(f) for f in feats]
+    rois = rois.contiguous().float()
+    n, c = feats[0].shape[0], feats[0].shape[1]
+    r = rois.shape[0]
+    out = torch.empty((r, c, pooled, pooled), dtype=torch.float32, device=rois.device).contiguous(
+        memory_format=torch.channels_last)
+    if r == 0:
+        return out
+    nl = len(feats)
+    ptrs = (C.c_void_p * nl)(*[f.data_ptr() for f in feats])
+    hs = (C.c_int32 * nl)(*[f.shape[2] for f in feats])
+    ws = (C.c_int32 * nl)(*[f.shape[3] for f in feats])
+    sc = (C.c_float * nl)(*[float(s) for s in scales])
+    _lib.check(_lib.lib().wd_roi_pool_fpn_f32(ptrs, hs, ws, sc, C.c_int(nl), C.c_int(c), C.c_int(n), _p(rois), C.c_int(r),
+                                              C.c_int(pooled), C.c_int(min_level), C.c_int(canonical_level),
+                                              C.c_float(canonical_size), _p(out), _stream()), 'wd_roi_pool_fpn_f32')
+    return out
+
+
+_nms_ws = {}
+
+
+def nms_sorted(boxes, idxs, iou_threshold):
+    """boxes (n,4) xyxy already sorted by descending score; idxs (n) int32 group ids or None -> bool keep mask."""
+    n = boxes.shape[0]
+    keep = torch.zeros(n, dtype=torch.uint8, device=boxes.device)
+    if n == 0:
+        return keep.bool()
+    boxes = boxes.contiguous().float()
+    if idxs is not None:
+        idxs = idxs.contiguous().to(torch.int32)
+    lib = _lib.lib()
+    need = int(lib.wd_nms_workspace(C.c_int(n)))
+    key = (boxes.device, torch.cuda.current_stream().cuda_stream)
+    ws = _nms_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=boxes.device)
+        _nms_ws[key] = ws
+    cnt = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    _lib.check(lib.wd_nms_sorted_f32(_p(boxes), _p(idxs), C.c_int(n), C.c_float(iou_threshold), _p(keep), _p(cnt),
+                                     _p(ws), C.c_size_t(ws.numel()), _stream()), 'wd_nms_sorted_f32')
+    return keep.bool()
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """detectron2.layers.batched_nms / torchvision.ops.nms: indices of the kept boxes, descending score."""
+    if boxes.shape[0] == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    keep = nms_sorted(boxes[order], None if idxs is None else idxs[order], iou_threshold)
+    return order[keep]
+
+
+def nms(boxes, scores, iou_threshold):
+    return batched_nms(boxes, scores, None, iou_threshold)
+
+
+def deform_pack_weight(weight, groups):
+    """(C_out, C_in/groups, 3, 3) -> packed [group][tap][ci][co] float32 buffer for deform_conv3x3."""
+    weight = weight.detach().contiguous().float()
+    c_out, cg = weight.shape[0], weight.shape[1]
+    c_in = cg * groups
+    lib = _lib.lib()
+    lib.wd_deform_packed_weight_floats.restype = C.c_size_t
+    n = int(lib.wd_deform_packed_weight_floats(C.c_int(c_in), C.c_int(c_out), C.c_int(groups)))
+    if n == 0:
+        raise ValueError('deform_pack_weight: needs C_in == C_out divisible by groups')
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    _lib.check(lib.wd_deform_pack_weight(_p(weight), C.c_int(c_in), C.c_int(c_out), C.c_int(groups), _p(packed), _stream()),
+               'wd_deform_pack_weight')
+    return packed
+
+
+def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None, bias=None, relu=False, mask=None):
+    """detectron2 DeformConv (3x3, dilation 1, deformable_groups 1) + fused FrozenBN affine / ReLU.
+    x (N,C,H,W), offset (N,18,Ho,Wo), optional mask (N,9,Ho,Wo); returns (N,C,Ho,Wo) channels_last."""
+    x = _nhwc(x)
+    offset = _nhwc(offset)
+    if mask is not None:
+        mask = _nhwc(mask)
+    n, c, h, w = x.shape
+    ho = (h + 2 * pad - 3) // stride + 1
+    wo = (w + 2 * pad - 3) // stride + 1
+    assert offset.shape == (n, 18, ho, wo), (offset.shape, (n, 18, ho, wo))
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    _lib.check(_lib.lib().wd_deform_conv3x3_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
+                                                C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+                                                C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad), _p(y), _stream()),
+               'wd_deform_conv3x3_f32')
+    return y
+
+
+def gemm_nt(a, bt, bias=None, residual=None, relu=False, out=None):
+    """act(a (M,K) @ bt (N,K)^T + bias [+ residual]) on the f32 matrix cores."""
+    a = a.contiguous().float()
+    bt = bt.contiguous().float()
+    m, k = a.shape
+    n = bt.shape[0]
+    assert bt.shape[1] == k
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if residual is not None:
+        residual = residual.contiguous()
+    _lib.check(_lib.lib().wd_gemm_nt_f32(_p(a), _p(bt), _p(bias), _p(residual), C.c_int(1 if relu else 0), C.c_int(m),
+                                         C.c_int(n), C.c_int(k), _p(out), _stream()), 'wd_gemm_nt_f32')
+    return out
