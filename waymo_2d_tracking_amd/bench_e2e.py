@@ -1,0 +1,102 @@
+"""End-to-end detect -> SORT step used by bench.py (BASELINE.json metric) and by smoke().
+
+One step = one 5-camera chunk: `frames_per_step` synthetic 1920x1280x3 uint8 frames already resident in HBM go
+through the Cascade R-CNN X152-FPN detector one by one (batch 1, like the reference's --batch-size=1); their <= 100
+detections per frame are converted on the device to the detection-JSON wire values (int box, 5-decimal score,
+category) and written into the frame-slotted SoA layout of wt_track_streams_dev; then every (camera, class) tracker
+runs as one wavefront of the persistent SORT kernel.  Nothing leaves the GPU inside the timed region.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .detnet.nn.detectron2_det import Detectron2Det, detections_to_wire
+from .tracking.utils import make_params
+
+SLOTS = 100          # detectron2 TEST.DETECTIONS_PER_IMAGE (top-100, detectron2_det via fast_rcnn_inference)
+
+
+class DetectTrackPipeline(object):
+    def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
+                 iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0):
+        self.dev = torch.device(device)
+        self.nc, self.fpc, self.h, self.w = n_cameras, frames_per_camera, height, width
+        self.model = Detectron2Det(seed=seed).to(self.dev).eval()
+        self.n_frames = n_cameras * frames_per_camera
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        self.frames = torch.randint(0, 256, (self.n_frames, height, width, 3), generator=g, dtype=torch.uint8).to(self.dev)
+        n = self.n_frames * SLOTS
+        self.x = torch.zeros(n, dtype=torch.float64, device=self.dev)
+        self.y = torch.zeros_like(self.x); self.wd = torch.zeros_like(self.x); self.ht = torch.zeros_like(self.x)
+        self.score = torch.zeros_like(self.x)
+        self.category = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        self.frame_off = (torch.arange(self.n_frames + 1, dtype=torch.int64) * SLOTS).to(self.dev)
+        self.stream_off = (torch.arange(n_cameras + 1, dtype=torch.int64) * frames_per_camera).to(self.dev)
+        self.clip_w = torch.full((n_cameras,), float(width), dtype=torch.float64, device=self.dev)
+        self.clip_h = torch.full((n_cameras,), float(height), dtype=torch.float64, device=self.dev)
+        self.params, self._keep = make_params(max_age, min_hits, list(score_threshold), list(iou_threshold))
+        self.lib = _lib.lib()
+        ws = int(self.lib.wt_track_streams_workspace(C.c_int64(n), C.c_int64(self.n_frames), C.c_int32(n_cameras),
+                                                     C.c_int64(SLOTS), C.byref(self.params)))
+        self.ws = torch.empty(ws, dtype=torch.uint8, device=self.dev)
+        self.out_frame = torch.empty(n + 1, dtype=torch.int64, device=self.dev)
+        self.out_cat = torch.empty(n + 1, dtype=torch.int32, device=self.dev)
+        self.out_bbox = torch.empty((n + 1, 4), dtype=torch.float64, device=self.dev)
+        self.out_score = torch.empty(n + 1, dtype=torch.float64, device=self.dev)
+        self.out_id = torch.empty(n + 1, dtype=torch.int64, device=self.dev)
+        self.counts = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self.n_dets_last = 0
+
+    def detect_frame(self, f):
+        """Frame f (camera-major order) -> wire-format detections written into slots [f*100, f*100+100)."""
+        img = self.frames[f].permute(2, 0, 1).unsqueeze(0).float()           # ToTensor(scaling=False): 0..255 RGB
+        (boxes, scores, classes), = self.model.predict_device(img)
+        xywh, score, cat = detections_to_wire(boxes, scores, classes, self.w, self.h)
+        k = xywh.shape[0]
+        a = f * SLOTS
+        self.category[a:a + SLOTS] = 0                                          # unused slots: category 0 = ignored
+        self.x[a:a + k] = xywh[:, 0]; self.y[a:a + k] = xywh[:, 1]
+        self.wd[a:a + k] = xywh[:, 2]; self.ht[a:a + k] = xywh[:, 3]
+        self.score[a:a + k] = score
+        self.category[a:a + k] = cat
+        return k
+
+    def track(self):
+        p = lambda t: C.c_void_p(t.data_ptr())
+        n = self.n_frames * SLOTS
+        rc = self.lib.wt_track_streams_dev(
+            C.c_int64(n), p(self.x), p(self.y), p(self.wd), p(self.ht), p(self.score), p(self.category),
+            C.c_int64(self.n_frames), p(self.frame_off), C.c_int32(self.nc), p(self.stream_off), p(self.clip_w),
+            p(self.clip_h), C.c_int64(SLOTS), C.byref(self.params), C.c_int64(0), p(self.out_frame), p(self.out_cat),
+            p(self.out_bbox), p(self.out_score), p(self.out_id), p(self.counts), C.c_void_p(self.counts.data_ptr() + 8),
+            p(self.ws), C.c_size_t(self.ws.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, 'wt_track_streams_dev')
+
+    def step(self, with_tracking=True):
+        total = 0
+        for f in range(self.n_frames):
+            total += self.detect_frame(f)
+        if with_tracking:
+            self.track()
+        self.n_dets_last = total
+        return total
+
+
+def run(args, world, rank, timed_steps):
+    fps = max(1, args.frames_per_step // 5)
+    pipe = DetectTrackPipeline(5, fps, seed=rank)
+    steps = args.steps or 3
+    warmup = args.warmup if args.warmup is not None else 1
+    track = args.stage == 'e2e'
+    dt, ev_ms = timed_steps(world, lambda: pipe.step(track), steps, warmup)
+    n_out, births = [int(v) for v in pipe.counts.cpu().tolist()]
+    frames = pipe.n_frames
+    res = dict(value=frames * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, dtype='f32',
+               workload='Cascade R-CNN X152-32x8d-FPN dconv (random-init, fp32, batch 1) on synthetic 1920x1280x3 frames'
+                        ' -> top-100 detections/frame -> %s; %d cameras x %d frames per step per GPU'
+                        % ('SORT (max_age 2, min_hits 0, all boxes tracked)' if track else 'no tracking', 5, fps),
+               extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births))
+    return res, steps, warmup

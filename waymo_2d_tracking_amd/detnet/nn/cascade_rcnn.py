@@ -1,0 +1,315 @@
+"""Cascade R-CNN X-152-32x8d-FPN (GN heads, deformable conv in res3-res5), inference graph for MI355X.
+
+This is the detector the reference builds through detectron2's
+``Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml`` with the mask head off
+(/root/reference/detnet/nn/detectron2_det/__init__.py:21-60); the layer shapes follow the module tree printed in
+/root/reference/logs/12442/job.log:336-1221 and the op semantics SURVEY.md App. C (detectron2 is not vendored:
+"parity unpinned", weights are random-initialised unless a state dict is loaded).
+
+MI355X-first layout: every activation is NHWC (torch.channels_last storage); FrozenBatchNorm is folded into the
+producing op; the hot per-frame ops run in hand-written HIP kernels (detnet/nn/ops.py):
+  * every 1x1 convolution (2/3 of the backbone FLOPs) and the box-head FC = one f32-MFMA GEMM with fused
+    bias / residual add / ReLU epilogue (wd_gemm_nt_f32),
+  * the 47 deformable 3x3 convolutions = implicit GEMM with fused FrozenBN + ReLU (wd_deform_conv3x3_f32),
+  * ROIPooler over the 4 FPN levels (wd_roi_pool_fpn_f32), RPN / box NMS (wd_nms_sorted_f32).
+Dense 3x3 / 7x7 convolutions and GroupNorm stay on PyTorch-ROCm (MIOpen) - the "Python host carries the graph".
+"""
+import math
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+
+BLOCKS = (3, 8, 36, 3)            # job.log:354,402,528,1074
+STAGE_CH = (256, 512, 1024, 2048)
+GROUPS = 32
+PIXEL_MEAN = (103.530, 116.280, 123.675)     # BGR, detectron2 defaults for the IN5k C2 weights
+PIXEL_STD = (57.375, 57.120, 58.395)
+SCALE_CLAMP = math.log(1000.0 / 16)
+
+
+def _msra(shape, gen, fan_out=True):
+    w = torch.empty(shape)
+    fan = shape[0] * shape[2] * shape[3] if fan_out else shape[1] * shape[2] * shape[3]
+    return w.normal_(0, math.sqrt(2.0 / fan), generator=gen)
+
+
+class Conv1x1(nn.Module):
+    """1x1 conv (+ folded FrozenBN or bias) [+ residual] [+ ReLU] as one MFMA GEMM on the NHWC matrix view."""
+
+    def __init__(self, cin, cout, gen, bn_scale=1.0, bias=False):
+        super().__init__()
+        w = _msra((cout, cin, 1, 1), gen).view(cout, cin)
+        # FrozenBN(weight=bn_scale, bias=0, mean=0, var=1, eps=1e-5) folded: w * scale, bias 0
+        s = bn_scale / math.sqrt(1.0 + 1e-5) if not bias else 1.0
+        self.weight = nn.Parameter(w * s, requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+
+    def forward(self, x, relu=False, residual=None, stride=1):
+        if stride != 1:
+            x = x[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)
+        n, c, h, w = x.shape
+        a = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
+        r = None if residual is None else residual.permute(0, 2, 3, 1).reshape(n * h * w, -1)
+        y = ops.gemm_nt(a, self.weight, self.bias, r, relu)
+        return y.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+class ConvBN(nn.Module):
+    """Dense / grouped kxk conv with folded FrozenBN (MIOpen)."""
+
+    def __init__(self, cin, cout, k, stride, pad, groups, gen, bias=False):
+        super().__init__()
+        w = _msra((cout, cin // groups, k, k), gen)
+        s = 1.0 / math.sqrt(1.0 + 1e-5) if not bias else 1.0
+        self.weight = nn.Parameter((w * s).contiguous(memory_format=torch.channels_last), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+        self.stride, self.pad, self.groups = stride, pad, groups
+
+    def forward(self, x, relu=False):
+        y = F.conv2d(x, self.weight, self.bias, self.stride, self.pad, 1, self.groups)
+        return F.relu_(y) if relu else y
+
+
+class Bottleneck(nn.Module):
+    """BottleneckBlock / DeformBottleneckBlock, STRIDE_IN_1X1=False (job.log:357-419)."""
+
+    def __init__(self, cin, cout, stride, deform, gen, offset_std):
+        super().__init__()
+        width = cout                      # 32x8d: bottleneck width == stage output channels (job.log:363-376)
+        self.stride, self.deform = stride, deform
+        self.shortcut = Conv1x1(cin, cout, gen) if cin != cout else None
+        self.conv1 = Conv1x1(cin, width, gen)
+        if deform:
+            self.conv2_offset = ConvBN(width, 18, 3, stride, 1, 1, gen, bias=True)
+            # detectron2 zero-initialises the offset conv; random-init benchmarks scale it so that offsets are a
+            # few pixels (a zero offset field would make the gather trivially regular)
+            self.conv2_offset.weight.data.normal_(0, offset_std, generator=gen)
+            w = _msra((width, width // GROUPS, 3, 3), gen)
+            self.conv2_weight = nn.Parameter(w, requires_grad=False)
+            self.conv2_scale = nn.Parameter(torch.full((width,), 1.0 / math.sqrt(1.0 + 1e-5)), requires_grad=False)
+            self.conv2_bias = nn.Parameter(torch.zeros(width), requires_grad=False)
+            self._packed = None
+        else:
+            self.conv2 = ConvBN(width, width, 3, stride, 1, GROUPS, gen)
+        self.conv3 = Conv1x1(width, cout, gen, bn_scale=0.25)   # keeps random-init activations bounded over 50 blocks
+
+    def packed_weight(self):
+        if self._packed is None or self._packed.device != self.conv2_weight.device:
+            self._packed = ops.deform_pack_weight(self.conv2_weight, GROUPS)
+        return self._packed
+
+    def forward(self, x):
+        sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)
+        out = self.conv1(x, relu=True)
+        if self.deform:
+            offset = self.conv2_offset(out)
+            out = ops.deform_conv3x3(out, offset, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
+                                     self.conv2_bias, relu=True)
+        else:
+            out = self.conv2(out, relu=True)
+        return self.conv3(out, relu=True, residual=sc)
+
+
+class ResNeXt152FPN(nn.Module):
+    def __init__(self, gen, offset_std=0.01):
+        super().__init__()
+        self.stem = ConvBN(3, 64, 7, 2, 3, 1, gen)
+        stages = []
+        cin = 64
+        for si, (nb, cout) in enumerate(zip(BLOCKS, STAGE_CH)):
+            blocks = []
+            for b in range(nb):
+                stride = 2 if (b == 0 and si > 0) else 1
+                blocks.append(Bottleneck(cin, cout, stride, si > 0, gen, offset_std))   # DEFORM_ON_PER_STAGE F,T,T,T
+                cin = cout
+            stages.append(nn.Sequential(*blocks))
+        self.res2, self.res3, self.res4, self.res5 = stages
+        self.lateral = nn.ModuleList([Conv1x1(c, 256, gen, bias=True) for c in STAGE_CH])
+        self.output = nn.ModuleList([ConvBN(256, 256, 3, 1, 1, 1, gen, bias=True) for _ in STAGE_CH])
+
+    def forward(self, x):
+        x = self.stem(x, relu=True)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        c2 = self.res2(x); c3 = self.res3(c2); c4 = self.res4(c3); c5 = self.res5(c4)
+        feats = [c2, c3, c4, c5]
+        prev = self.lateral[3](c5)
+        outs = [self.output[3](prev)]
+        for i in (2, 1, 0):                                  # top-down pathway, nearest x2, fuse "sum"
+            top = F.interpolate(prev, scale_factor=2.0, mode='nearest')
+            prev = self.lateral[i](feats[i], residual=top.contiguous(memory_format=torch.channels_last))
+            outs.insert(0, self.output[i](prev))
+        p6 = F.max_pool2d(outs[3], kernel_size=1, stride=2, padding=0)     # LastLevelMaxPool
+        return outs + [p6]                                    # p2..p6
+
+
+def apply_deltas(deltas, boxes, weights):
+    """detectron2 Box2BoxTransform.apply_deltas (class-agnostic (R,4) deltas)."""
+    wx, wy, ww, wh = weights
+    widths = boxes[:, 2] - boxes[:, 0]
+    heights = boxes[:, 3] - boxes[:, 1]
+    ctr_x = boxes[:, 0] + 0.5 * widths
+    ctr_y = boxes[:, 1] + 0.5 * heights
+    dx = deltas[:, 0] / wx
+    dy = deltas[:, 1] / wy
+    dw = torch.clamp(deltas[:, 2] / ww, max=SCALE_CLAMP)
+    dh = torch.clamp(deltas[:, 3] / wh, max=SCALE_CLAMP)
+    pcx = dx * widths + ctr_x
+    pcy = dy * heights + ctr_y
+    pw = torch.exp(dw) * widths
+    ph = torch.exp(dh) * heights
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=1)
+
+
+def clip_boxes(boxes, h, w):
+    x1 = boxes[:, 0].clamp(min=0, max=w); y1 = boxes[:, 1].clamp(min=0, max=h)
+    x2 = boxes[:, 2].clamp(min=0, max=w); y2 = boxes[:, 3].clamp(min=0, max=h)
+    return torch.stack((x1, y1, x2, y2), dim=1)
+
+
+class RPN(nn.Module):
+    """StandardRPNHead + DefaultAnchorGenerator + find_top_rpn_proposals (job.log:1126-1135;
+    detectron2_det/configs/Base-RCNN-FPN.yaml:10-20: sizes 32..512, ratios .5/1/2, 1000 pre / 1000 post, NMS 0.7)."""
+    SIZES = (32, 64, 128, 256, 512)
+    RATIOS = (0.5, 1.0, 2.0)
+    STRIDES = (4, 8, 16, 32, 64)
+
+    def __init__(self, gen, pre_nms_topk=1000, post_nms_topk=1000, nms_thresh=0.7):
+        super().__init__()
+        self.conv = ConvBN(256, 256, 3, 1, 1, 1, gen, bias=True)
+        self.conv.weight.data.normal_(0, 0.01, generator=gen)
+        self.objectness = Conv1x1(256, 3, gen, bias=True)
+        self.objectness.weight.data.normal_(0, 0.01, generator=gen)
+        self.deltas = Conv1x1(256, 12, gen, bias=True)
+        self.deltas.weight.data.normal_(0, 0.01, generator=gen)
+        self.pre, self.post, self.thr = pre_nms_topk, post_nms_topk, nms_thresh
+        self._anchors = {}
+
+    def anchors(self, level, h, w, device):
+        key = (level, h, w, device)
+        if key not in self._anchors:
+            size, stride = self.SIZES[level], self.STRIDES[level]
+            cell = []
+            for r in self.RATIOS:
+                aw = math.sqrt(size * size / r)
+                ah = r * aw
+                cell.append([-aw / 2, -ah / 2, aw / 2, ah / 2])
+            cell = torch.tensor(cell, dtype=torch.float32, device=device)
+            sx = torch.arange(0, w * stride, stride, dtype=torch.float32, device=device)
+            sy = torch.arange(0, h * stride, stride, dtype=torch.float32, device=device)
+            yy, xx = torch.meshgrid(sy, sx, indexing='ij')
+            shifts = torch.stack((xx, yy, xx, yy), dim=-1).reshape(-1, 1, 4)
+            self._anchors[key] = (shifts + cell.view(1, -1, 4)).reshape(-1, 4)     # (H*W*A, 4)
+        return self._anchors[key]
+
+    def forward(self, feats, img_h, img_w):
+        """feats p2..p6 (batch 1) -> proposals (R,4), sorted by objectness."""
+        boxes_l, scores_l, lvl_l = [], [], []
+        for l, f in enumerate(feats):
+            t = self.conv(f, relu=True)
+            logits = self.objectness(t)                    # (1,3,H,W) channels_last == (H,W,A) order in memory
+            deltas = self.deltas(t)                        # (1,12,H,W)
+            h, w = f.shape[2], f.shape[3]
+            logits = logits.permute(0, 2, 3, 1).reshape(-1)
+            deltas = deltas.permute(0, 2, 3, 1).reshape(-1, 4)
+            k = min(self.pre, logits.numel())
+            top, idx = torch.topk(logits, k, sorted=True)
+            prop = apply_deltas(deltas[idx], self.anchors(l, h, w, f.device)[idx], (1.0, 1.0, 1.0, 1.0))
+            boxes_l.append(prop); scores_l.append(top)
+            lvl_l.append(torch.full((k,), l, dtype=torch.int32, device=f.device))
+        boxes = clip_boxes(torch.cat(boxes_l), img_h, img_w)
+        scores = torch.cat(scores_l); lvls = torch.cat(lvl_l)
+        ok = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
+        boxes, scores, lvls = boxes[ok], scores[ok], lvls[ok]
+        keep = ops.batched_nms(boxes, scores, lvls, self.thr)[: self.post]
+        return boxes[keep]
+
+
+class BoxHead(nn.Module):
+    """FastRCNNConvFCHead (4 x conv3x3+GN32+ReLU, fc1 12544->1024) + FastRCNNOutputLayers (job.log:1146-1218)."""
+
+    def __init__(self, num_classes, gen):
+        super().__init__()
+        self.convs = nn.ModuleList([nn.Conv2d(256, 256, 3, 1, 1, bias=False) for _ in range(4)])
+        self.norms = nn.ModuleList([nn.GroupNorm(32, 256) for _ in range(4)])
+        for c in self.convs:
+            c.weight.data.copy_(_msra((256, 256, 3, 3), gen))
+        # fc1 weight is stored for the NHWC flatten order (ph, pw, c); a checkpoint in detectron2's (c, ph, pw) order
+        # is permuted once by load_state_dict_detectron2()
+        self.fc1_weight = nn.Parameter(torch.empty(1024, 12544).normal_(0, math.sqrt(1.0 / 12544), generator=gen),
+                                       requires_grad=False)
+        self.fc1_bias = nn.Parameter(torch.zeros(1024), requires_grad=False)
+        self.cls_weight = nn.Parameter(torch.empty(num_classes + 1, 1024).normal_(0, 0.01, generator=gen), requires_grad=False)
+        self.cls_bias = nn.Parameter(torch.zeros(num_classes + 1), requires_grad=False)
+        self.box_weight = nn.Parameter(torch.empty(4, 1024).normal_(0, 0.001, generator=gen), requires_grad=False)
+        self.box_bias = nn.Parameter(torch.zeros(4), requires_grad=False)
+
+    def forward(self, x):
+        for conv, norm in zip(self.convs, self.norms):
+            x = F.relu_(norm(conv(x)))
+        r = x.shape[0]
+        flat = x.permute(0, 2, 3, 1).reshape(r, -1)           # NHWC flatten, a view
+        h = ops.gemm_nt(flat, self.fc1_weight, self.fc1_bias, None, True)
+        logits = F.linear(h, self.cls_weight, self.cls_bias)
+        deltas = F.linear(h, self.box_weight, self.box_bias)
+        return logits, deltas
+
+
+class CascadeRCNN(nn.Module):
+    CASCADE_WEIGHTS = ((10.0, 10.0, 5.0, 5.0), (20.0, 20.0, 10.0, 10.0), (30.0, 30.0, 15.0, 15.0))
+
+    def __init__(self, num_classes=4, seed=0, score_thresh=0.01, nms_thresh=0.5, topk=100, offset_std=0.01):
+        super().__init__()
+        gen = torch.Generator().manual_seed(seed)
+        self.num_classes = num_classes
+        self.backbone = ResNeXt152FPN(gen, offset_std)
+        self.rpn = RPN(gen)
+        self.heads = nn.ModuleList([BoxHead(num_classes, gen) for _ in range(3)])
+        self.score_thresh, self.nms_thresh, self.topk = score_thresh, nms_thresh, topk   # detectron2_det/__init__.py:53
+        self.register_buffer('pixel_mean', torch.tensor(PIXEL_MEAN).view(1, 3, 1, 1))
+        self.register_buffer('pixel_std', torch.tensor(PIXEL_STD).view(1, 3, 1, 1))
+        self.to(memory_format=torch.channels_last)
+
+    def preprocess(self, image_bgr):
+        """(1,3,H,W) float 0..255 BGR -> normalised, zero-padded to a multiple of 32 (size_divisibility), NHWC."""
+        x = (image_bgr - self.pixel_mean) / self.pixel_std
+        h, w = x.shape[2], x.shape[3]
+        ph, pw = (32 - h % 32) % 32, (32 - w % 32) % 32
+        if ph or pw:
+            x = F.pad(x, (0, pw, 0, ph))
+        return x.contiguous(memory_format=torch.channels_last)
+
+    @torch.no_grad()
+    def forward(self, image_bgr):
+        """One image (1,3,H,W) -> (boxes (K,4) xyxy pixels, scores (K), classes (K) int64), K <= topk."""
+        img_h, img_w = image_bgr.shape[2], image_bgr.shape[3]
+        feats = self.backbone(self.preprocess(image_bgr))
+        proposals = self.rpn(feats, img_h, img_w)
+        scales = [1.0 / s for s in (4, 8, 16, 32)]
+        stage_scores = []
+        boxes = proposals
+        for k in range(3):
+            if k > 0:
+                boxes = clip_boxes(boxes, img_h, img_w)
+            rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
+            pooled = ops.roi_pool_fpn(feats[:4], rois, scales, 7, 2, 4, 224.0)
+            logits, deltas = self.heads[k](pooled)
+            stage_scores.append(F.softmax(logits, dim=-1))
+            boxes = apply_deltas(deltas, boxes, self.CASCADE_WEIGHTS[k])
+        scores = (stage_scores[0] + stage_scores[1] + stage_scores[2]) * (1.0 / 3)
+        return self.inference(boxes, scores, img_h, img_w)
+
+    def inference(self, boxes, scores, img_h, img_w):
+        """detectron2 fast_rcnn_inference_single_image (class-agnostic boxes)."""
+        valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+        boxes, scores = boxes[valid], scores[valid]
+        scores = scores[:, :-1]
+        boxes = clip_boxes(boxes, img_h, img_w)
+        mask = scores > self.score_thresh
+        inds = mask.nonzero()
+        b = boxes[inds[:, 0]]
+        s = scores[mask]
+        keep = ops.batched_nms(b, s, inds[:, 1].to(torch.int32), self.nms_thresh)[: self.topk]
+        return b[keep], s[keep], inds[keep, 1]
