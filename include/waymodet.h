@@ -61,6 +61,9 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
 int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias, const float* residual, int relu,
                    int M, int N, int K, float* C, void* stream);
 
+/* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
+int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@ class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
                  iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0):
         self.dev = torch.device(device)
+        torch.backends.cudnn.benchmark = True      # the reference's --cudnn-benchmark: let MIOpen pick its fastest conv
         self.nc, self.fpc, self.h, self.w = n_cameras, frames_per_camera, height, width
         self.model = Detectron2Det(seed=seed).to(self.dev).eval()
         self.n_frames = n_cameras * frames_per_camera

@@ -37,7 +37,12 @@ def _msra(shape, gen, fan_out=True):
 
 
 class Conv1x1(nn.Module):
-    """1x1 conv (+ folded FrozenBN or bias) [+ residual] [+ ReLU] as one MFMA GEMM on the NHWC matrix view."""
+    """1x1 conv (+ folded FrozenBN or bias) [+ residual] [+ ReLU] = one GEMM on the NHWC matrix view.
+
+    Plain library GEMM (hipBLASLt through torch): on MI355X it sustains 100-135 TFLOP/s fp32 on these shapes
+    (tools/gemm_bench.py), ahead of the hand-written wd_gemm_nt_f32 which is kept for the box-head FC.  The residual
+    rides on the GEMM's beta term (addmm), bias+ReLU on the library epilogue where there is no residual."""
+    USE_LIBRARY_GEMM = True
 
     def __init__(self, cin, cout, gen, bn_scale=1.0, bias=False):
         super().__init__()
@@ -53,7 +58,16 @@ class Conv1x1(nn.Module):
         n, c, h, w = x.shape
         a = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
         r = None if residual is None else residual.permute(0, 2, 3, 1).reshape(n * h * w, -1)
-        y = ops.gemm_nt(a, self.weight, self.bias, r, relu)
+        if not self.USE_LIBRARY_GEMM:
+            y = ops.gemm_nt(a, self.weight, self.bias, r, relu)
+        elif r is None:
+            if relu:
+                y = torch._addmm_activation(self.bias, a, self.weight.t(), use_gelu=False)
+            else:
+                y = torch.addmm(self.bias, a, self.weight.t())
+        else:
+            y = torch.addmm(r, a, self.weight.t())
+            y = ops.bias_relu_(y, self.bias, relu)
         return y.view(n, h, w, -1).permute(0, 3, 1, 2)
 
 

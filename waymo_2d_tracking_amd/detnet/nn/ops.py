@@ -134,3 +134,11 @@ def gemm_nt(a, bt, bias=None, residual=None, relu=False, out=None):
     _lib.check(_lib.lib().wd_gemm_nt_f32(_p(a), _p(bt), _p(bias), _p(residual), C.c_int(1 if relu else 0), C.c_int(m),
                                          C.c_int(n), C.c_int(k), _p(out), _stream()), 'wd_gemm_nt_f32')
     return out
+
+
+def bias_relu_(y, bias, relu=True):
+    """In-place y = act(y + bias[col]) on a row-major (M,N) matrix: the epilogue pass behind a library GEMM."""
+    m, n = y.shape
+    _lib.check(_lib.lib().wd_bias_relu_f32(_p(y), _p(bias), C.c_long(m), C.c_int(n), C.c_int(1 if relu else 0), _stream()),
+               'wd_bias_relu_f32')
+    return y
