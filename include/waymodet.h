@@ -61,6 +61,11 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
 int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias, const float* residual, int relu,
                    int M, int N, int K, float* C, void* stream);
 
+/* GroupNorm(groups, C, eps) + optional ReLU, in place, on n items of (HW, C) NHWC float32 (HW <= 64): the norm of
+ * FastRCNNConvFCHead (job.log:1149-1150).  Biased variance, like torch.nn.GroupNorm. */
+int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const float* beta, int n, int hw, int c, int groups,
+                               float eps, int relu, void* stream);
+
 /* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
 int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
 

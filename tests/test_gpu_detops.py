@@ -107,3 +107,14 @@ def test_gemm_vs_reference(M, N, K, relu):
     got2 = ops.gemm_nt(a.cuda(), bt.cuda())
     exp2 = a.cuda().double() @ bt.cuda().double().t()
     assert (got2.double() - exp2).abs().max().item() < 2e-4
+
+
+def test_groupnorm_relu_vs_torch():
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((37, 256, 7, 7), generator=g) * 3 + 1
+    w = torch.rand(256, generator=g) + 0.5
+    b = torch.randn(256, generator=g)
+    exp = torch.relu(torch.nn.functional.group_norm(x.double(), 32, w.double(), b.double(), 1e-5))
+    got = ops.groupnorm_relu_(_cl(x), w.cuda(), b.cuda(), 32)
+    np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-5)

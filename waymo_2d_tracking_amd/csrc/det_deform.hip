@@ -22,8 +22,8 @@ constexpr int CCH = 128;        // channels per workgroup
 constexpr int LDC = CCH + 2;    // LDS row stride of the im2col slab
 
 struct Sample {
-    int idx[4];     // input pixel index (h*W + w) of the 4 corners, -1 = outside
-    float wgt[4];
+    int idx[4];     // input pixel index (n*H*W + h*W + w) of the 4 corners; corners outside the image point at
+    float wgt[4];   // pixel 0 with weight 0, so the gather issues all its loads unconditionally (no branches)
 };
 
 template <int CG>
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void deform_conv3x3_kernel(
         const long gp = p0 + p;
         Sample s;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s.idx[q] = -1; s.wgt[q] = 0.f; }
+        for (int q = 0; q < 4; ++q) { s.idx[q] = 0; s.wgt[q] = 0.f; }
         if (gp < npix) {
             const int n = (int)(gp / ((long)Ho * Wo));
             const int rem = (int)(gp - (long)n * Ho * Wo);
@@ -83,13 +83,13 @@ __global__ __launch_bounds__(256) void deform_conv3x3_kernel(
         for (int i = 0; i < TP / 8; ++i) {
             const int p = gp0 + 8 * i;
             const Sample s = tab[p * 9 + k];
+            float4 t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (s.idx[q] >= 0) {
-                    const float4 t = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
-                    v.x += s.wgt[q] * t.x; v.y += s.wgt[q] * t.y; v.z += s.wgt[q] * t.z; v.w += s.wgt[q] * t.w;
-                }
+                v.x += s.wgt[q] * t[q].x; v.y += s.wgt[q] * t[q].y; v.z += s.wgt[q] * t[q].z; v.w += s.wgt[q] * t[q].w;
             }
             float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
             d[0] = make_float2(v.x, v.y);

@@ -16,7 +16,67 @@ __global__ __launch_bounds__(256) void bias_relu_kernel(float4* __restrict__ y, 
     }
 }
 
+// GroupNorm + ReLU in place on (R, HW, C) NHWC rows (box-head GN(32, 256) after each 3x3 conv, job.log:1150).
+// One workgroup per ROI, one thread per channel: the HW (<= 64) values of a channel stay in registers, group
+// statistics are reduced across the CPG lanes of the group with xor-shuffles (two-pass mean / variance).
+template <int CPG>
+__global__ __launch_bounds__(256) void groupnorm_relu_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int HW, int C, float eps,
+                                                             int relu) {
+    float* base = x + (size_t)blockIdx.x * HW * C;
+    for (int c = threadIdx.x; c < C; c += 256) {            // C is a multiple of CPG; 256 % CPG == 0
+        float v[64];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            v[i] = (i < HW) ? base[(size_t)i * C + c] : 0.f;
+            s += v[i];
+        }
+#pragma unroll
+        for (int o = 1; o < CPG; o <<= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)(HW * CPG);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float d = (i < HW) ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+#pragma unroll
+        for (int o = 1; o < CPG; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q / (float)(HW * CPG) + eps);
+        const float g = gamma[c] * rstd, b = beta[c] - mean * gamma[c] * rstd;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            if (i < HW) {
+                float y = v[i] * g + b;
+                if (relu) y = fmaxf(y, 0.f);
+                base[(size_t)i * C + c] = y;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const float* beta, int n, int hw, int c, int groups,
+                                          float eps, int relu, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (n <= 0) return WT_OK;
+    const int cpg = groups > 0 ? c / groups : 0;
+    if (groups <= 0 || c % groups || hw < 1 || hw > 64 || c % 64) {
+        wt::set_error("wd_groupnorm_relu_nhwc_f32: need hw <= 64, C %% 64 == 0, C %% groups == 0 (hw=%d C=%d groups=%d)", hw, c, groups);
+        return WT_ERR_INVALID;
+    }
+#define WD_GN(CPG) hipLaunchKernelGGL(groupnorm_relu_kernel<CPG>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, hw, c, eps, relu)
+    if (cpg == 8) WD_GN(8);
+    else if (cpg == 4) WD_GN(4);
+    else if (cpg == 16) WD_GN(16);
+    else if (cpg == 32) WD_GN(32);
+    else { wt::set_error("wd_groupnorm_relu_nhwc_f32: channels per group must be 4, 8, 16 or 32 (got %d)", cpg); return WT_ERR_INVALID; }
+#undef WD_GN
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
 
 extern "C" int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream) {
     WT_TRY(wt::ensure_device());

@@ -65,14 +65,15 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
         }
         if (i < n) keep[i] = (kept >> lane) & 1ull;
         total += __popcll(kept);
-        // OR the kept rows into the words of the later tiles
+        // OR the kept rows into the words of the later tiles: every lane owns words w, w+64, ...; the 64 row loads
+        // per word are independent (suppressed rows are masked out, not branched around) so they pipeline
         for (int w = b + 1 + lane; w < nb; w += 64) {
             unsigned long long acc = removed[w];
-            unsigned long long kk = kept;
-            while (kk) {
-                const int t = __builtin_ctzll(kk);
-                kk &= kk - 1;
-                acc |= mask[(size_t)(b * 64 + t) * nb + w];
+            const unsigned long long* col = mask + (size_t)(b * 64) * nb + w;
+#pragma unroll 16
+            for (int t = 0; t < 64; ++t) {
+                const unsigned long long v = (t < cnt) ? col[(size_t)t * nb] : 0ull;
+                acc |= ((kept >> t) & 1ull) ? v : 0ull;
             }
             removed[w] = acc;
         }

@@ -262,7 +262,10 @@ class BoxHead(nn.Module):
 
     def forward(self, x):
         for conv, norm in zip(self.convs, self.norms):
-            x = F.relu_(norm(conv(x)))
+            x = conv(x)
+            if not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)
+            x = ops.groupnorm_relu_(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True)
         r = x.shape[0]
         flat = x.permute(0, 2, 3, 1).reshape(r, -1)           # NHWC flatten, a view
         h = ops.gemm_nt(flat, self.fc1_weight, self.fc1_bias, None, True)

@@ -32,8 +32,7 @@ def roi_pool_fpn(feats, rois, scales, pooled=7, min_level=2, canonical_level=4, 
     rois = rois.contiguous().float()
     n, c = feats[0].shape[0], feats[0].shape[1]
     r = rois.shape[0]
-    out = torch.empty((r, c, pooled, pooled), dtype=torch.float32, device=rois.device).contiguous(
-        memory_format=torch.channels_last)
+    out = torch.empty((r, c, pooled, pooled), dtype=torch.float32, device=rois.device, memory_format=torch.channels_last)
     if r == 0:
         return out
     nl = len(feats)
@@ -112,7 +111,7 @@ def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None
     ho = (h + 2 * pad - 3) // stride + 1
     wo = (w + 2 * pad - 3) // stride + 1
     assert offset.shape == (n, 18, ho, wo), (offset.shape, (n, 18, ho, wo))
-    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     _lib.check(_lib.lib().wd_deform_conv3x3_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
                                                 C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
                                                 C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad), _p(y), _stream()),
@@ -142,3 +141,13 @@ def bias_relu_(y, bias, relu=True):
     _lib.check(_lib.lib().wd_bias_relu_f32(_p(y), _p(bias), C.c_long(m), C.c_int(n), C.c_int(1 if relu else 0), _stream()),
                'wd_bias_relu_f32')
     return y
+
+
+def groupnorm_relu_(x, weight, bias, groups, eps=1e-5, relu=True):
+    """In-place GroupNorm (+ReLU) on an (R,C,H,W) channels_last tensor with H*W <= 64 (the 7x7 box-head maps)."""
+    assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32
+    r, c, h, w = x.shape
+    _lib.check(_lib.lib().wd_groupnorm_relu_nhwc_f32(_p(x), _p(weight), _p(bias), C.c_int(r), C.c_int(h * w), C.c_int(c),
+                                                     C.c_int(groups), C.c_float(eps), C.c_int(1 if relu else 0), _stream()),
+               'wd_groupnorm_relu_nhwc_f32')
+    return x
