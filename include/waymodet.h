@@ -43,7 +43,8 @@ int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_
 /* detectron2 DeformConv / ModulatedDeformConv forward (job.log:412-415), kernel 3x3, dilation 1,
  * deformable_groups 1:
  *   x      : (N, H, W, C_in) NHWC float32
- *   offset : (N, H_out, W_out, 18) NHWC float32, channel 2k = dy, 2k+1 = dx of tap k = kh*3+kw
+ *   offset : (N, H_out, W_out, 18) NHWC float32, channel 2k = dy, 2k+1 = dx of tap k = kh*3+kw;
+ *            NULL = no deformation: an ordinary grouped 3x3 convolution (res2 blocks, job.log:367-370)
  *   mask   : (N, H_out, W_out, 9) or NULL (non-modulated)
  *   weight : packed by wd_deform_pack_weight from the (C_out, C_in/groups, 3, 3) OIHW tensor
  *   scale/bias (C_out) or NULL: fused per-channel affine (FrozenBatchNorm2d) ; relu != 0 fuses ReLU

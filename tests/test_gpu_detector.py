@@ -1,0 +1,80 @@
+"""Whole-graph parity of the HIP-backed Cascade R-CNN X152-FPN against the CPU restatement oracle/detector_ref.py
+(same random-init parameters, small image).  float32 on both sides; tolerances are relative to the tensor's scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def models():
+    from waymo_2d_tracking_amd.detnet.nn.cascade_rcnn import CascadeRCNN
+    cpu = CascadeRCNN(seed=3, offset_std=0.02).eval()
+    gpu = CascadeRCNN(seed=3, offset_std=0.02).eval().cuda()
+    return cpu, gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def test_backbone_heads_and_detections_match_reference(models):
+    from oracle import detector_ref as R
+    cpu, gpu = models
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (1, 3, 160, 224), generator=g).float()
+    (rb, rs, rc), ref = R.forward(cpu, img, return_intermediates=True)
+    inter = {}
+    gb, gs, gc = gpu(img.cuda(), intermediates=inter)
+    # FPN features p2..p6
+    for lvl, (a, b) in enumerate(zip(inter['feats'], ref['feats'])):
+        assert a.shape == b.shape
+        assert _rel(a, b) < 2e-4, (lvl, _rel(a, b))
+    # same proposals into both cascades: logits / deltas of every stage
+    inter2 = {}
+    gpu(img.cuda(), proposals=ref['proposals'].cuda(), intermediates=inter2)
+    (_, _, _), ref2 = R.forward(cpu, img, return_intermediates=True, proposals=ref['proposals'])
+    for k in range(3):
+        assert _rel(inter2['stage_out'][k][0], ref2['stage_out'][k][0]) < 1e-3, k
+        assert _rel(inter2['stage_out'][k][1], ref2['stage_out'][k][1]) < 1e-3, k
+    np.testing.assert_allclose(inter2['boxes'].cpu().numpy(), ref2['boxes'].numpy(), rtol=0, atol=5e-3)   # pixels
+    np.testing.assert_allclose(inter2['scores'].cpu().numpy(), ref2['scores'].numpy(), rtol=0, atol=1e-4)
+    # end to end (RPN + NMS decisions included): the same number of detections, matching boxes
+    assert gb.shape[0] == rb.shape[0] <= 100
+    assert inter['proposals'].shape[0] == ref['proposals'].shape[0]
+    d = torch.cdist(gb.cpu().double(), rb.double(), p=1).min(dim=1).values
+    assert (d < 0.05).float().mean().item() > 0.95
+
+
+def test_predict_contract(models):
+    """Detectron2Det.predict: [per class] (n,5) float32 [score, cx, cy, w, h] normalised (detectron2_det/__init__.py:119-135)."""
+    from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
+    m = Detectron2Det(seed=1).eval().cuda()
+    x = torch.randint(0, 256, (2, 3, 128, 160)).float()
+    out = m.predict(x)
+    assert len(out) == 2 and all(len(o) == 4 for o in out)
+    for per_class in out:
+        for arr in per_class:
+            assert arr.ndim == 2 and arr.shape[1] == 5
+            if len(arr):
+                assert arr.dtype == np.float32
+                assert (arr[:, 1:3] >= 0).all() and (arr[:, 1:3] <= 1).all()
+        assert sum(len(a) for a in per_class) <= 100
+
+
+def test_tta_x15_hflip_roundtrip(models):
+    """--tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image; cx is mirrored back."""
+    from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
+    from waymo_2d_tracking_amd.detnet.nn.tta import TTA
+    m = Detectron2Det(seed=1).eval().cuda()
+    x = torch.randint(0, 256, (1, 3, 96, 128)).float().cuda()
+    big = torch.flip(torch.nn.functional.interpolate(x, scale_factor=1.5, mode='bilinear', align_corners=False), [3])
+    direct = m.predict(big)
+    via = TTA(m, ['x1.5', 'hflip']).predict(x)
+    for a, b in zip(direct[0], via[0]):
+        assert a.shape == b.shape
+        if len(a):
+            np.testing.assert_allclose(1 - a[:, 1], b[:, 1], atol=1e-6)
+            np.testing.assert_allclose(a[:, [0, 2, 3, 4]], b[:, [0, 2, 3, 4]], atol=1e-6)

@@ -71,6 +71,18 @@ def test_deform_conv_zero_offset_equals_grouped_conv():
     np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('C,stride', [(256, 1), (512, 2), (1024, 1)])
+def test_grouped_conv_without_offsets(C, stride):
+    """offset=None: plain grouped 3x3 conv (res2 path, 8 channels per group at C=256) vs torch conv in float64."""
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn((2, C, 19, 23), generator=g)
+    weight = torch.randn((C, C // 32, 3, 3), generator=g) / (3 * (C // 32) ** 0.5)
+    exp = torch.nn.functional.conv2d(x.double(), weight.double(), None, stride, 1, 1, 32)
+    got = ops.deform_conv3x3(_cl(x), None, ops.deform_pack_weight(weight.cuda(), 32), 32, stride, 1)
+    np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize('n', [1, 63, 64, 65, 500, 3000])
 def test_nms_vs_reference(n):
     from oracle import detops_ref as R

@@ -26,8 +26,8 @@ struct Sample {
     float wgt[4];   // pixel 0 with weight 0, so the gather issues all its loads unconditionally (no branches)
 };
 
-template <int CG>
-__global__ __launch_bounds__(256) void deform_conv3x3_kernel(
+template <int CG, bool DEFORM>
+__global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
     const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
     const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ bias, int relu,
     int batch, int H, int W, int C, int Cout, int Ho, int Wo, int stride, int pad, float* __restrict__ y) {
@@ -35,8 +35,33 @@ __global__ __launch_bounds__(256) void deform_conv3x3_kernel(
     __shared__ __attribute__((aligned(16))) float col[TP * LDC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long npix = (long)batch * Ho * Wo;
-    const long p0 = (long)blockIdx.x * TP;
-    const int c0 = blockIdx.y * CCH;             // first input (= output) channel of this chunk
+    // XCD-aware work mapping (speed only): workgroup b is dispatched to XCD b % 8, whose private 4 MiB L2 should see
+    // a compact slice of the input.  The gather re-reads every input pixel ~9x per channel chunk, so each XCD gets
+    // whole channel chunks (>= 8 chunks) or a contiguous range of pixel tiles of one chunk (< 8 chunks); its
+    // working set is then (pixels in flight) x 128 channels instead of the whole feature map.
+    const int ntiles = (int)((npix + TP - 1) / TP);
+    const int nchunks = C / CCH;
+    int tile, chunk;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        if (nchunks >= 8 && (nchunks & 7) == 0) {
+            const int cpx = nchunks >> 3;                    // chunks per XCD
+            chunk = xcd * cpx + slot % cpx;
+            tile = slot / cpx;
+        } else if (nchunks < 8 && (8 % nchunks) == 0 && (ntiles % (8 / nchunks)) == 0) {
+            const int xpc = 8 / nchunks;                     // XCDs per chunk
+            const int tpp = ntiles / xpc;                    // tiles per XCD
+            chunk = xcd / xpc;
+            tile = (xcd % xpc) * tpp + slot;
+        } else {
+            chunk = b / ntiles;
+            tile = b - chunk * ntiles;
+        }
+    }
+    if (tile >= ntiles || chunk >= nchunks) return;
+    const long p0 = (long)tile * TP;
+    const int c0 = chunk * CCH;                  // first input (= output) channel of this chunk
     // ---- 1. sampling table ----
     for (int e = tid; e < TP * 9; e += 256) {
         const int p = e / 9, k = e - 9 * p;
@@ -49,6 +74,12 @@ __global__ __launch_bounds__(256) void deform_conv3x3_kernel(
             const int rem = (int)(gp - (long)n * Ho * Wo);
             const int ho = rem / Wo, wo = rem - ho * Wo;
             const int kh = k / 3, kw = k - 3 * kh;
+            if (!DEFORM) {                    // plain grouped 3x3 convolution: one integer tap, zero padding
+                const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+                if (hi >= 0 && hi < H && wi >= 0 && wi < W) { s.idx[0] = n * H * W + hi * W + wi; s.wgt[0] = 1.f; }
+                tab[e] = s;
+                continue;
+            }
             const float* off = offset + (size_t)gp * 18;
             const float h_im = (float)(ho * stride - pad + kh) + off[2 * k];
             const float w_im = (float)(wo * stride - pad + kw) + off[2 * k + 1];
@@ -78,40 +109,70 @@ __global__ __launch_bounds__(256) void deform_conv3x3_kernel(
     const int gp0 = tid >> 5;          // first pixel row (rows gp0, gp0 + 8, ...)
     const int co_w = wave * 32;        // this wave's 32 output channels inside the chunk
     for (int k = 0; k < 9; ++k) {
-        // ---- 2. gather + blend the tap's im2col slab ----
+        // ---- 2. gather + blend the tap's im2col slab: 16 independent 16-byte loads in flight per lane ----
 #pragma unroll
-        for (int i = 0; i < TP / 8; ++i) {
-            const int p = gp0 + 8 * i;
-            const Sample s = tab[p * 9 + k];
-            float4 t[4];
+        for (int half = 0; half < 2; ++half) {
+            constexpr int NQ = DEFORM ? 4 : 1;
+            float4 t[4][NQ];
+            float wq[4][NQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 4; ++i) {
+                const int p = gp0 + 8 * (half * 4 + i);
+                const Sample s = tab[p * 9 + k];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v.x += s.wgt[q] * t[q].x; v.y += s.wgt[q] * t[q].y; v.z += s.wgt[q] * t[q].z; v.w += s.wgt[q] * t[q].w;
+                for (int q = 0; q < NQ; ++q) {
+                    t[i][q] = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
+                    wq[i][q] = s.wgt[q];
+                }
             }
-            float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = gp0 + 8 * (half * 4 + i);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    v.x += wq[i][q] * t[i][q].x; v.y += wq[i][q] * t[i][q].y;
+                    v.z += wq[i][q] * t[i][q].z; v.w += wq[i][q] * t[i][q].w;
+                }
+                float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
+                d[0] = make_float2(v.x, v.y);
+                d[1] = make_float2(v.z, v.w);
+            }
         }
         __syncthreads();
         // ---- 3. MFMA: out[64 px][32 co of this wave] += slab[64 px][ci of the group] * W[ci][co] ----
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int co_l = co_w + 16 * nt;                 // first co of this N tile inside the chunk
-            const int g_l = co_l / CG;                       // group inside the chunk
-            const int g = (c0 + co_l) / CG;                  // global group
-            const int co_g = (co_l % CG) + (lane & 15);      // co inside the group
-            const float* wb = wp + ((size_t)(g * 9 + k) * CG) * CG + co_g;
+            if (CG >= 16) {
+                const int g_l = co_l / CG;                       // group inside the chunk
+                const int g = (c0 + co_l) / CG;                  // global group
+                const int co_g = (co_l % CG) + (lane & 15);      // co inside the group
+                const float* wb = wp + ((size_t)(g * 9 + k) * CG) * CG + co_g;
 #pragma unroll
-            for (int kk = 0; kk < CG / 4; ++kk) {
-                const int ci = kk * 4 + (lane >> 4);
-                const float b = wb[(size_t)ci * CG];
+                for (int kk = 0; kk < CG / 4; ++kk) {
+                    const int ci = kk * 4 + (lane >> 4);
+                    const float b = wb[(size_t)ci * CG];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const float a = col[(mt * 16 + (lane & 15)) * LDC + g_l * CG + ci];
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float a = col[(mt * 16 + (lane & 15)) * LDC + g_l * CG + ci];
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            } else {
+                // CG == 8: the 16-wide N tile spans two groups -> block-diagonal B over the 16 input channels
+                const int j = lane & 15;
+                const int g = (c0 + co_l) / 8 + (j >> 3);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ci = kk * 4 + (lane >> 4);         // 0..15 inside the tile's channel range
+                    const float wv = wp[((size_t)(g * 9 + k) * 8 + (ci & 7)) * 8 + (j & 7)];
+                    const float b = ((ci >> 3) == (j >> 3)) ? wv : 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float a = col[(mt * 16 + (lane & 15)) * LDC + co_l + ci];
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt][nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -184,16 +245,26 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
     const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
     if (ho < 1 || wo < 1) return WT_OK;
     const long npix = (long)batch * ho * wo;
-    dim3 grid((unsigned)((npix + TP - 1) / TP), (unsigned)(c_in / CCH));
+    // 1-D grid, padded to a multiple of 8 so that the (xcd, slot) decomposition covers every (tile, chunk) pair
+    const long ntiles = (npix + TP - 1) / TP;
+    const long nwg = ntiles * (c_in / CCH);
+    dim3 grid((unsigned)((nwg + 7) / 8 * 8));
     hipStream_t stream = (hipStream_t)stream_;
-#define WD_LAUNCH(CG)                                                                                              \
-    hipLaunchKernelGGL(deform_conv3x3_kernel<CG>, grid, dim3(256), 0, stream, x, offset, mask, packed_weight, scale, \
-                       bias, relu, batch, h, w, c_in, c_out, ho, wo, stride, pad, y)
+#define WD_LAUNCH(CG)                                                                                                     \
+    do {                                                                                                                  \
+        if (offset)                                                                                                       \
+            hipLaunchKernelGGL((deform_conv3x3_kernel<CG, true>), grid, dim3(256), 0, stream, x, offset, mask,           \
+                               packed_weight, scale, bias, relu, batch, h, w, c_in, c_out, ho, wo, stride, pad, y);       \
+        else                                                                                                              \
+            hipLaunchKernelGGL((deform_conv3x3_kernel<CG, false>), grid, dim3(256), 0, stream, x, offset, mask,          \
+                               packed_weight, scale, bias, relu, batch, h, w, c_in, c_out, ho, wo, stride, pad, y);       \
+    } while (0)
     if (cg == 16) WD_LAUNCH(16);
     else if (cg == 32) WD_LAUNCH(32);
     else if (cg == 64) WD_LAUNCH(64);
+    else if (cg == 8) WD_LAUNCH(8);
     else {
-        wt::set_error("wd_deform_conv3x3_f32: channels per group must be 16, 32 or 64 (got %d)", cg);
+        wt::set_error("wd_deform_conv3x3_f32: channels per group must be 8, 16, 32 or 64 (got %d)", cg);
         return WT_ERR_INVALID;
     }
 #undef WD_LAUNCH

@@ -107,7 +107,11 @@ class Bottleneck(nn.Module):
             self.conv2_bias = nn.Parameter(torch.zeros(width), requires_grad=False)
             self._packed = None
         else:
-            self.conv2 = ConvBN(width, width, 3, stride, 1, GROUPS, gen)
+            # plain grouped 3x3 (res2): the same implicit-GEMM kernel without the sampling offsets
+            self.conv2_weight = nn.Parameter(_msra((width, width // GROUPS, 3, 3), gen), requires_grad=False)
+            self.conv2_scale = nn.Parameter(torch.full((width,), 1.0 / math.sqrt(1.0 + 1e-5)), requires_grad=False)
+            self.conv2_bias = nn.Parameter(torch.zeros(width), requires_grad=False)
+            self._packed = None
         self.conv3 = Conv1x1(width, cout, gen, bn_scale=0.25)   # keeps random-init activations bounded over 50 blocks
 
     def packed_weight(self):
@@ -123,7 +127,8 @@ class Bottleneck(nn.Module):
             out = ops.deform_conv3x3(out, offset, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
                                      self.conv2_bias, relu=True)
         else:
-            out = self.conv2(out, relu=True)
+            out = ops.deform_conv3x3(out, None, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
+                                     self.conv2_bias, relu=True)
         return self.conv3(out, relu=True, residual=sc)
 
 
@@ -299,13 +304,17 @@ class CascadeRCNN(nn.Module):
         return x.contiguous(memory_format=torch.channels_last)
 
     @torch.no_grad()
-    def forward(self, image_bgr):
-        """One image (1,3,H,W) -> (boxes (K,4) xyxy pixels, scores (K), classes (K) int64), K <= topk."""
+    def forward(self, image_bgr, proposals=None, intermediates=None):
+        """One image (1,3,H,W) -> (boxes (K,4) xyxy pixels, scores (K), classes (K) int64), K <= topk.
+        `proposals` overrides the RPN output and `intermediates` (a dict) receives feature maps / stage outputs:
+        both are test hooks."""
         img_h, img_w = image_bgr.shape[2], image_bgr.shape[3]
         feats = self.backbone(self.preprocess(image_bgr))
-        proposals = self.rpn(feats, img_h, img_w)
+        if proposals is None:
+            proposals = self.rpn(feats, img_h, img_w)
         scales = [1.0 / s for s in (4, 8, 16, 32)]
         stage_scores = []
+        stage_out = []
         boxes = proposals
         for k in range(3):
             if k > 0:
@@ -313,9 +322,12 @@ class CascadeRCNN(nn.Module):
             rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
             pooled = ops.roi_pool_fpn(feats[:4], rois, scales, 7, 2, 4, 224.0)
             logits, deltas = self.heads[k](pooled)
+            stage_out.append((logits, deltas))
             stage_scores.append(F.softmax(logits, dim=-1))
             boxes = apply_deltas(deltas, boxes, self.CASCADE_WEIGHTS[k])
         scores = (stage_scores[0] + stage_scores[1] + stage_scores[2]) * (1.0 / 3)
+        if intermediates is not None:
+            intermediates.update(feats=feats, proposals=proposals, stage_out=stage_out, boxes=boxes, scores=scores)
         return self.inference(boxes, scores, img_h, img_w)
 
     def inference(self, boxes, scores, img_h, img_w):

@@ -104,13 +104,14 @@ def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None
     """detectron2 DeformConv (3x3, dilation 1, deformable_groups 1) + fused FrozenBN affine / ReLU.
     x (N,C,H,W), offset (N,18,Ho,Wo), optional mask (N,9,Ho,Wo); returns (N,C,Ho,Wo) channels_last."""
     x = _nhwc(x)
-    offset = _nhwc(offset)
+    if offset is not None:
+        offset = _nhwc(offset)
     if mask is not None:
         mask = _nhwc(mask)
     n, c, h, w = x.shape
     ho = (h + 2 * pad - 3) // stride + 1
     wo = (w + 2 * pad - 3) // stride + 1
-    assert offset.shape == (n, 18, ho, wo), (offset.shape, (n, 18, ho, wo))
+    assert offset is None or offset.shape == (n, 18, ho, wo), (offset.shape, (n, 18, ho, wo))
     y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     _lib.check(_lib.lib().wd_deform_conv3x3_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
                                                 C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
