@@ -259,93 +259,166 @@ __device__ __forceinline__ void track_init(const TrackerMem& M, int slot, const 
 }
 
 // ---- scikit-learn 0.22.2 Munkres (call site sort.py:206) on one wavefront ----------------------------------
+// State (LDS): the float32 cost matrix C (n x m, n <= m, odd leading dimension ld so that a wave reading one column of
+// 32 consecutive rows hits 32 distinct banks), one 64-bit zero bitmap word per (row, 64 columns) and the star /
+// prime index arrays.  Row and column covers live in registers: lane w owns cover word w (64 rows / columns each).
+// All full-matrix passes are row-parallel (lane = row, sequential over the row's columns); the search for "the first
+// uncovered zero in row-major order" is a ballot over rows of (zero word & ~column cover) followed by a ctz.
 struct MunkresMem {       // LDS
     int* row_star;        // [n]  column of the star in the row, -1 none
     int* col_star;        // [m]
     int* row_prime;       // [n]
-    unsigned char* row_cov;
-    unsigned char* col_cov;
+    unsigned long long* zmask;   // [n][W]  bit c of word w: C[r][64 w + c] == 0
 };
 
-// C: n x m float32 (n <= m), modified in place.  Returns 0, or 5 when the iteration guard trips.
+__host__ __device__ inline int munkres_ld(int m) { return m | 1; }
+__host__ __device__ inline size_t munkres_lds_bytes(int n_small, int n_big) {
+    const size_t w = (size_t)(n_big + 63) / 64;
+    return (((size_t)(2 * n_small + n_big) * sizeof(int) + 7) / 8) * 8 + (size_t)n_small * w * 8 + 16;
+}
+__device__ __forceinline__ MunkresMem munkres_mem(char* lds, int n_small, int n_big) {
+    MunkresMem L;
+    int* ip = reinterpret_cast<int*>(lds);
+    L.row_star = ip;
+    L.row_prime = ip + n_small;
+    L.col_star = ip + 2 * n_small;
+    const size_t off = (((size_t)(2 * n_small + n_big) * sizeof(int) + 7) / 8) * 8;
+    L.zmask = reinterpret_cast<unsigned long long*>(lds + off);
+    return L;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// C: n x m float32 with leading dimension ld (n <= m <= 4096), modified in place.  Returns 0 or kErrNumeric.
 template <class CostPtr>
-__device__ int munkres_wave(CostPtr C, int n, int m, const MunkresMem& L) {
+__device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L) {
     const int lane = threadIdx.x & 63;
-    for (int r = lane; r < n; r += kWave) { L.row_star[r] = -1; L.row_prime[r] = -1; L.row_cov[r] = 0; }
-    for (int c = lane; c < m; c += kWave) { L.col_star[c] = -1; L.col_cov[c] = 0; }
-    __syncthreads();
-    // step 1: subtract row minima; star the first zero of each row whose column is still free (row-major)
-    for (int r = 0; r < n; ++r) {
-        float mn = __builtin_inff();
-        for (int c = lane; c < m; c += kWave) { const float v = C[r * m + c]; mn = (v < mn) ? v : mn; }
-        mn = wave_min_f(mn);
-        int first = -1;
-        for (int base = 0; base < m; base += kWave) {
-            const int c = base + lane;
-            bool z = false;
-            if (c < m) {
-                const float v = C[r * m + c] - mn;
-                C[r * m + c] = v;
-                z = (v == 0.f) && !L.col_cov[c];
+    const int W = (m + 63) >> 6;
+    for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;
+    // step 1: subtract row minima and build the zero bitmaps (row-parallel)
+    for (int r0 = 0; r0 < n; r0 += kWave) {
+        const int r = r0 + lane;
+        if (r < n) {
+            float mn = C[r * ld];
+            for (int c = 1; c < m; ++c) { const float v = C[r * ld + c]; mn = (v < mn) ? v : mn; }
+            for (int w = 0; w < W; ++w) {
+                unsigned long long z = 0ull;
+                const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                for (int c = 0; c < c1; ++c) {
+                    const float v = C[r * ld + 64 * w + c] - mn;
+                    C[r * ld + 64 * w + c] = v;
+                    z |= (v == 0.f) ? (1ull << c) : 0ull;
+                }
+                L.zmask[(size_t)r * W + w] = z;
             }
-            const unsigned long long mask = __ballot(z);
-            if (mask && first < 0) first = base + __builtin_ctzll(mask);
+            L.row_star[r] = -1;
+            L.row_prime[r] = -1;
         }
-        if (first >= 0 && lane == 0) { L.row_star[r] = first; L.col_star[first] = r; L.col_cov[first] = 1; }
-        __syncthreads();
     }
+    __syncthreads();
+    // greedy stars in row-major order (serial over rows; lane w keeps column-cover word w)
+    unsigned long long colcov = 0ull, rowcov = 0ull;
+    for (int r = 0; r < n; ++r) {
+        int first = -1;
+        for (int w = 0; w < W && first < 0; ++w) {
+            const unsigned long long a = L.zmask[(size_t)r * W + w] & ~readlane64(colcov, w);
+            if (a) first = 64 * w + __builtin_ctzll(a);
+        }
+        if (first >= 0) {
+            if (lane == 0) { L.row_star[r] = first; L.col_star[first] = r; }
+            if (lane == (first >> 6)) colcov |= 1ull << (first & 63);
+        }
+    }
+    __syncthreads();
     long guard = 0;
     const long guard_max = 64L + 8L * (long)(n + m) * (long)(n + m) * (long)(n + 1);
     for (;;) {
-        // step 3
+        // step 3: cover the starred columns; done when every row has a star
         int stars = 0;
-        for (int base = 0; base < m; base += kWave) {
-            const int c = base + lane;
-            const bool st = (c < m) && L.col_star[c] >= 0;
-            if (c < m) L.col_cov[c] = st ? 1 : 0;
-            stars += __popcll(__ballot(st));
+        colcov = 0ull;
+        for (int w = 0; w < W; ++w) {
+            const int c = 64 * w + lane;
+            const unsigned long long word = __ballot((c < m) && L.col_star[c] >= 0);
+            if (lane == w) colcov = word;
+            stars += __popcll(word);
         }
-        for (int r = lane; r < n; r += kWave) L.row_cov[r] = 0;
-        __syncthreads();
+        rowcov = 0ull;
         if (stars >= n) return 0;
         // step 4 (+ step 6)
         int z0r = -1, z0c = -1;
         for (;;) {
-            if (++guard > guard_max) return 5;
+            if (++guard > guard_max) return kErrNumeric;
             int fr = -1, fc = -1;
-            for (int r = 0; r < n && fr < 0; ++r) {
-                if (L.row_cov[r]) continue;
-                for (int base = 0; base < m; base += kWave) {
-                    const int c = base + lane;
-                    const bool z = (c < m) && !L.col_cov[c] && (C[r * m + c] == 0.f);
-                    const unsigned long long mask = __ballot(z);
-                    if (mask) { fr = r; fc = base + __builtin_ctzll(mask); break; }
+            for (int r0 = 0; r0 < n && fr < 0; r0 += kWave) {
+                const int r = r0 + lane;
+                const unsigned long long rc = readlane64(rowcov, r0 >> 6);
+                bool has = false;
+                if (r < n && !((rc >> lane) & 1ull))
+                    for (int w = 0; w < W; ++w) has = has || ((L.zmask[(size_t)r * W + w] & ~readlane64(colcov, w)) != 0ull);
+                const unsigned long long mask = __ballot(has);
+                if (mask) fr = r0 + __builtin_ctzll(mask);
+            }
+            if (fr >= 0) {
+                for (int w = 0; w < W && fc < 0; ++w) {
+                    const unsigned long long a = L.zmask[(size_t)fr * W + w] & ~readlane64(colcov, w);
+                    if (a) fc = 64 * w + __builtin_ctzll(a);
                 }
             }
             if (fr < 0) {
-                // step 6
+                // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
                 float mn = __builtin_inff();
-                bool any_r = false;
-                for (int r = 0; r < n; ++r) {
-                    if (L.row_cov[r]) continue;
-                    any_r = true;
-                    for (int c = lane; c < m; c += kWave)
-                        if (!L.col_cov[c]) { const float v = C[r * m + c]; mn = (v < mn) ? v : mn; }
+                bool any_r = false, any_c = false;
+                for (int w = 0; w < W; ++w) {
+                    const unsigned long long cw = readlane64(colcov, w);
+                    const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                    const unsigned long long valid = (c1 == 64) ? ~0ull : ((1ull << c1) - 1ull);
+                    any_c = any_c || ((~cw & valid) != 0ull);
                 }
-                bool any_c = false;
-                for (int base = 0; base < m; base += kWave) {
-                    const int c = base + lane;
-                    any_c = any_c || (__ballot((c < m) && !L.col_cov[c]) != 0ull);
+                for (int r0 = 0; r0 < n; r0 += kWave) {
+                    const int r = r0 + lane;
+                    const unsigned long long rc = readlane64(rowcov, r0 >> 6);
+                    const bool unc = (r < n) && !((rc >> lane) & 1ull);
+                    any_r = any_r || (__ballot(unc) != 0ull);
+                    if (unc)
+                        for (int w = 0; w < W; ++w) {
+                            unsigned long long todo = ~readlane64(colcov, w);
+                            const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                            if (c1 < 64) todo &= (1ull << c1) - 1ull;
+                            while (todo) {
+                                const int c = __builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                                const float v = C[r * ld + 64 * w + c];
+                                mn = (v < mn) ? v : mn;
+                            }
+                        }
                 }
                 mn = wave_min_f(mn);
                 if (any_r && any_c) {
-                    for (int r = 0; r < n; ++r) {
-                        const bool rc = L.row_cov[r] != 0;
-                        for (int c = lane; c < m; c += kWave) {
-                            float v = C[r * m + c];
-                            if (rc) v = v + mn;
-                            if (!L.col_cov[c]) v = v - mn;
-                            C[r * m + c] = v;
+                    for (int r0 = 0; r0 < n; r0 += kWave) {
+                        const int r = r0 + lane;
+                        const unsigned long long rc = readlane64(rowcov, r0 >> 6);
+                        if (r < n) {
+                            const bool rcov = (rc >> lane) & 1ull;
+                            for (int w = 0; w < W; ++w) {
+                                const unsigned long long cw = readlane64(colcov, w);
+                                const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                                unsigned long long z = 0ull;
+                                for (int c = 0; c < c1; ++c) {
+                                    float v = C[r * ld + 64 * w + c];
+                                    const bool ccov = (cw >> c) & 1ull;
+                                    if (rcov || !ccov) {
+                                        if (rcov) v = v + mn;
+                                        if (!ccov) v = v - mn;
+                                        C[r * ld + 64 * w + c] = v;
+                                    }
+                                    z |= (v == 0.f) ? (1ull << c) : 0ull;
+                                }
+                                L.zmask[(size_t)r * W + w] = z;
+                            }
                         }
                     }
                 }
@@ -355,11 +428,11 @@ __device__ int munkres_wave(CostPtr C, int n, int m, const MunkresMem& L) {
             const int sc = uni(L.row_star[fr]);
             if (lane == 0) L.row_prime[fr] = fc;
             if (sc < 0) { z0r = fr; z0c = fc; break; }
-            if (lane == 0) { L.row_cov[fr] = 1; L.col_cov[sc] = 0; }
-            __syncthreads();
+            if (lane == (fr >> 6)) rowcov |= 1ull << (fr & 63);
+            if (lane == (sc >> 6)) colcov &= ~(1ull << (sc & 63));
         }
         __syncthreads();
-        // step 5: augmenting path (serial, lane 0)
+        // step 5: augmenting path (serial, lane 0); then erase primes
         if (lane == 0) {
             int pr = z0r, pc = z0c;
             for (long it = 0; it <= (long)n + m; ++it) {
@@ -425,23 +498,23 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
     if (T > 0 && N > 0) {
         const bool transposed = T < N;                 // Munkres works on rows <= cols
         const int n = transposed ? T : N, m = transposed ? N : T;
-        const bool in_lds = (long)n * m <= (long)lds_cost_cap;
+        const int ld = munkres_ld(m);
+        const bool in_lds = (long)n * ld <= (long)lds_cost_cap;
         if (!in_lds && !M.cost_g) return kErrCapacity;
         float* C = in_lds ? lds_cost : M.cost_g;
-        for (int r = 0; r < n; ++r) {
-            for (int c = lane; c < m; c += kWave) {
-                const int d = transposed ? c : r, t = transposed ? r : c;
-                float db[4];
-                dets.get(d, db);
-                double tb[4];
+        for (int e = lane; e < n * m; e += kWave) {
+            const int r = e / m, c = e - r * m;
+            const int d = transposed ? c : r, t = transposed ? r : c;
+            float db[4];
+            dets.get(d, db);
+            double tb[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tb[q] = M.pbox[q * cap + t];
-                const float v = (float)iou_det_trk(db, tb);          // stored float32 (sort.py:201,205)
-                C[r * m + c] = -v;                                     // linear_assignment(-iou_matrix)
-            }
+            for (int q = 0; q < 4; ++q) tb[q] = M.pbox[q * cap + t];
+            const float v = (float)iou_det_trk(db, tb);              // stored float32 (sort.py:201,205)
+            C[r * ld + c] = -v;                                        // linear_assignment(-iou_matrix)
         }
         __syncthreads();
-        const int rc = in_lds ? munkres_wave(lds_cost, n, m, L) : munkres_wave(M.cost_g, n, m, L);
+        const int rc = in_lds ? munkres_wave(lds_cost, n, m, ld, L) : munkres_wave(M.cost_g, n, m, ld, L);
         if (rc) return rc;
         for (int d = lane; d < N; d += kWave) {
             const int t = transposed ? L.col_star[d] : L.row_star[d];

@@ -18,7 +18,7 @@ using namespace wtdev;
 namespace {
 
 constexpr int kLdsCostFloats = 8192;          // 32 KiB of cost matrix in LDS per wave
-constexpr size_t kLdsMunkresMax = 24 * 1024;  // stars/primes/covers
+constexpr size_t kLdsMunkresMax = 120 * 1024;   // stars / primes / zero bitmaps (dynamic LDS, raised limit)  // stars/primes/covers
 
 struct Workspace {                       // device pointers carved from one block
     // per tracker
@@ -44,10 +44,6 @@ struct Workspace {                       // device pointers carved from one bloc
     size_t bytes;
 };
 
-size_t munkres_lds_bytes(int capN, int cap) {
-    return wt::align_up((size_t)(2 * capN + cap) * sizeof(int) + (size_t)capN + (size_t)cap, 16);
-}
-
 Workspace carve_ws(void* base, int64_t n_dets, int64_t n_frames, int32_t n_streams, int C, int cap, int capN,
                    bool need_cost_g) {
     wt::Carver cv(base);
@@ -67,7 +63,7 @@ Workspace carve_ws(void* base, int64_t n_dets, int64_t n_frames, int32_t n_strea
     w.det_match = cv.take<int>(nt * capN);
     w.new_list = cv.take<int>(nt * capN);
     w.det_idx = cv.take<int>(nt * capN);
-    w.cost_g = cv.take<float>(need_cost_g ? nt * (size_t)capN * cap : 1);
+    w.cost_g = cv.take<float>(need_cost_g ? nt * (size_t)capN * (cap | 1) : 1);
     w.first_key = cv.take<long long>(nt);
     w.cnt = cv.take<int>((size_t)n_frames * C);
     w.births = cv.take<int>((size_t)n_frames * C);
@@ -104,21 +100,10 @@ __device__ __forceinline__ TrackerMem tracker_mem(const Workspace& w, size_t tk,
     M.trk_match = w.trk_match + tk * cap;
     M.det_match = w.det_match + tk * capN;
     M.new_list = w.new_list + tk * capN;
-    M.cost_g = cost_g ? w.cost_g + tk * (size_t)capN * cap : nullptr;
+    M.cost_g = cost_g ? w.cost_g + tk * (size_t)capN * (cap | 1) : nullptr;
     M.cap = cap;
     M.capN = capN;
     return M;
-}
-
-__device__ __forceinline__ MunkresMem munkres_mem(char* lds, int capN, int cap) {
-    MunkresMem L;
-    int* ip = reinterpret_cast<int*>(lds);
-    L.row_star = ip;
-    L.row_prime = ip + capN;
-    L.col_star = ip + 2 * capN;
-    L.row_cov = reinterpret_cast<unsigned char*>(ip + 2 * capN + cap);
-    L.col_cov = L.row_cov + capN;
-    return L;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -177,7 +162,7 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
     const int s = (int)(tk / C);
     const int c = (int)(tk % C) + 1;
     float* lds_cost = reinterpret_cast<float*>(smem);
-    MunkresMem L = munkres_mem(smem + (size_t)lds_cost_cap * sizeof(float), capN, cap);
+    MunkresMem L = munkres_mem(smem + (((size_t)lds_cost_cap * sizeof(float) + 15) / 16) * 16, capN, cap);
     TrackerMem M = tracker_mem(ws, tk, cap, capN, have_cost_g);
     int* det_idx = ws.det_idx + tk * capN;
     for (int i = lane; i < cap; i += kWave) M.freel[i] = cap - 1 - i;
@@ -333,12 +318,12 @@ int pick_caps(int64_t max_frame_dets, const wt_track_params* p, int* cap, int* c
     if (c > (1 << 20)) { wt::set_error("per-tracker capacity too large (%lld tracks)", (long long)c); return WT_ERR_CAPACITY; }
     *capN = (int)n;
     *cap = (int)c;
-    const int64_t full = (int64_t)(*capN) * (*cap);
+    const int64_t full = (int64_t)(*capN) * ((*cap) | 1);
     *lds_cost = (int)(full < kLdsCostFloats ? full : kLdsCostFloats);
     *cost_g = full > kLdsCostFloats;
-    const size_t mk = munkres_lds_bytes(*capN, *cap);
+    const size_t mk = wtdev::munkres_lds_bytes(*capN, *cap);
     if (mk > kLdsMunkresMax) { wt::set_error("frame with %lld detections exceeds the LDS budget of the assignment kernel", (long long)n); return WT_ERR_CAPACITY; }
-    *lds_bytes = (size_t)(*lds_cost) * sizeof(float) + mk;
+    *lds_bytes = wt::align_up((size_t)(*lds_cost) * sizeof(float), 16) + mk;
     return WT_OK;
 }
 
@@ -388,6 +373,9 @@ int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const
     WT_HIP(hipMemsetAsync(ws.rcnt, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
     WT_HIP(hipMemsetAsync(ws.rbirths, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
     const unsigned n_trackers = (unsigned)n_streams * (unsigned)C;
+    if (lds > 48 * 1024)
+        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_streams_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(sort_streams_kernel, dim3(n_trackers), dim3(kWave), lds, stream, x, y, w, h, score, category,
                        frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
                        (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws);

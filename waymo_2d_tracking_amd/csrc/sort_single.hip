@@ -11,22 +11,7 @@ using namespace wtdev;
 namespace {
 
 constexpr int kLdsCostFloats = 8192;
-constexpr size_t kLdsMunkresMax = 24 * 1024;
-
-size_t munkres_lds_bytes(int n_small, int n_big) {
-    return wt::align_up((size_t)(2 * n_small + n_big) * sizeof(int) + (size_t)n_small + (size_t)n_big, 16);
-}
-
-__device__ __forceinline__ MunkresMem munkres_mem(char* lds, int n_small, int n_big) {
-    MunkresMem L;
-    int* ip = reinterpret_cast<int*>(lds);
-    L.row_star = ip;
-    L.row_prime = ip + n_small;
-    L.col_star = ip + 2 * n_small;
-    L.row_cov = reinterpret_cast<unsigned char*>(ip + 2 * n_small + n_big);
-    L.col_cov = L.row_cov + n_small;
-    return L;
-}
+constexpr size_t kLdsMunkresMax = 120 * 1024;   // stars / primes / zero bitmaps (dynamic LDS, raised limit)
 
 struct RowDets {
     const float* p;
@@ -56,7 +41,7 @@ __global__ __launch_bounds__(kWave) void sort_step_kernel(TrackerMem M, int* sta
                                                           int mk_small, int mk_big) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* lds_cost = reinterpret_cast<float*>(smem);
-    MunkresMem L = munkres_mem(smem + (size_t)lds_cost_cap * sizeof(float), mk_small, mk_big);
+    MunkresMem L = munkres_mem(smem + (((size_t)lds_cost_cap * sizeof(float) + 15) / 16) * 16, mk_small, mk_big);
     TrackerState S = {state[0], state[1], state[2], state[3]};
     __syncthreads();
     RowDets dets = {dets5};
@@ -113,14 +98,15 @@ __global__ __launch_bounds__(kWave) void assignment_kernel(const float* __restri
     const bool transposed = n_cols < n_rows;
     const int n = transposed ? n_cols : n_rows, m = transposed ? n_rows : n_cols;
     float* lds_cost = reinterpret_cast<float*>(smem);
-    MunkresMem L = munkres_mem(smem + (work_in_lds ? (size_t)n * m * sizeof(float) : 0), n, m);
+    const int ld = munkres_ld(m);
+    MunkresMem L = munkres_mem(smem + (work_in_lds ? (((size_t)n * ld * sizeof(float) + 15) / 16) * 16 : 0), n, m);
     float* C = work_in_lds ? lds_cost : work;
     for (int e = lane; e < n * m; e += kWave) {
         const int r = e / m, c = e - r * m;
-        C[e] = transposed ? cost[(size_t)c * n_cols + r] : cost[(size_t)r * n_cols + c];
+        C[r * ld + c] = transposed ? cost[(size_t)c * n_cols + r] : cost[(size_t)r * n_cols + c];
     }
     __syncthreads();
-    const int rc = work_in_lds ? munkres_wave(lds_cost, n, m, L) : munkres_wave(work, n, m, L);
+    const int rc = work_in_lds ? munkres_wave(lds_cost, n, m, ld, L) : munkres_wave(work, n, m, ld, L);
     int k = 0;
     if (rc == 0) {
         const unsigned long long lt = lanemask_lt();
@@ -156,7 +142,8 @@ __global__ __launch_bounds__(kWave) void associate_kernel(const float* __restric
         const bool transposed = T < N;
         const int n = transposed ? T : N, m = transposed ? N : T;
         float* lds_cost = reinterpret_cast<float*>(smem);
-        MunkresMem L = munkres_mem(smem + (work_in_lds ? (size_t)n * m * sizeof(float) : 0), n > 0 ? n : 1, m);
+        const int ld = munkres_ld(m);
+        MunkresMem L = munkres_mem(smem + (work_in_lds ? (((size_t)n * ld * sizeof(float) + 15) / 16) * 16 : 0), n > 0 ? n : 1, m);
         float* C = work_in_lds ? lds_cost : work;
         for (int r = 0; r < n; ++r)
             for (int c = lane; c < m; c += kWave) {
@@ -164,11 +151,11 @@ __global__ __launch_bounds__(kWave) void associate_kernel(const float* __restric
                 float db[4]; double tb[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { db[q] = dets5[5 * d + q]; tb[q] = trks4[4 * t + q]; }
-                C[r * m + c] = -(float)iou_det_trk(db, tb);
+                C[r * ld + c] = -(float)iou_det_trk(db, tb);
             }
         for (int t = lane; t < T; t += kWave) trk_flag[t] = 0;              // 0 never assigned, 1 matched, 2 rejected
         __syncthreads();
-        if (N > 0) rc = work_in_lds ? munkres_wave(lds_cost, n, m, L) : munkres_wave(work, n, m, L);
+        if (N > 0) rc = work_in_lds ? munkres_wave(lds_cost, n, m, ld, L) : munkres_wave(work, n, m, ld, L);
         if (rc == 0) {
             for (int d = lane; d < N; d += kWave) {
                 const int t = transposed ? L.col_star[d] : L.row_star[d];
@@ -309,7 +296,7 @@ int wt_sort_update_host(wt_sort* s, const float* dets5, int n, double iou_thresh
     const int small = n < T ? n : T, big = n < T ? T : n;
     const size_t mk = munkres_lds_bytes(small > 0 ? small : 1, big > 0 ? big : 1);
     if (mk > kLdsMunkresMax) { wt::set_error("assignment of %d x %d exceeds the LDS budget", n, T); return WT_ERR_CAPACITY; }
-    const size_t elems = (size_t)n * (size_t)T;
+    const size_t elems = (size_t)(small > 0 ? small : 1) * (size_t)((big > 0 ? big : 1) | 1);   // n x ld
     int lds_cost = (int)(elems <= (size_t)kLdsCostFloats ? elems : 0);
     TrackerMem M = s->M;
     M.det_match = s->dmatch.as<int>();
@@ -320,7 +307,13 @@ int wt_sort_update_host(wt_sort* s, const float* dets5, int n, double iou_thresh
         M.cost_g = s->cost.as<float>();
     }
     const long long id_base = wt_idctr_get(s->ctr);
-    hipLaunchKernelGGL(sort_step_kernel, dim3(1), dim3(kWave), (size_t)lds_cost * sizeof(float) + mk, nullptr, M,
+    {
+        const size_t lds = wt::align_up((size_t)lds_cost * sizeof(float), 16) + mk;
+        if (lds > 48 * 1024)
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_step_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(sort_step_kernel, dim3(1), dim3(kWave), wt::align_up((size_t)lds_cost * sizeof(float), 16) + mk, nullptr, M,
                        s->state.as<int>(), s->dets.as<float>(), n, iou_threshold, s->max_age, s->min_hits, id_base,
                        s->out.as<double>(), s->out_cap, s->result.as<int>(), lds_cost, small > 0 ? small : 1,
                        big > 0 ? big : 1);
@@ -362,15 +355,22 @@ int wt_linear_assignment_f32_host(const float* cost, int n_rows, int n_cols, int
     *n_pairs = 0;
     WT_TRY(wt::ensure_device());
     if (n_rows <= 0 || n_cols <= 0) return WT_OK;
-    const size_t elems = (size_t)n_rows * (size_t)n_cols;
     const int small = n_rows < n_cols ? n_rows : n_cols, big = n_rows < n_cols ? n_cols : n_rows;
+    const size_t elems = (size_t)small * (size_t)(big | 1);      // working matrix: n x ld
     const size_t mk = munkres_lds_bytes(small, big);
     if (mk > kLdsMunkresMax) { wt::set_error("assignment of %d x %d exceeds the LDS budget", n_rows, n_cols); return WT_ERR_CAPACITY; }
     const bool in_lds = elems <= (size_t)kLdsCostFloats;
     wt::DevBuf dc, dw, dp, dr;
-    WT_TRY(dc.alloc(4 * elems)); WT_TRY(dw.alloc(in_lds ? 16 : 4 * elems)); WT_TRY(dp.alloc(8 * (size_t)small)); WT_TRY(dr.alloc(16));
-    WT_HIP(hipMemcpy(dc.p, cost, 4 * elems, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(assignment_kernel, dim3(1), dim3(kWave), (in_lds ? 4 * elems : 0) + mk, nullptr, dc.as<float>(),
+    const size_t in_elems = (size_t)n_rows * (size_t)n_cols;
+    {
+        const size_t lds = (in_lds ? wt::align_up(4 * elems, 16) : 0) + mk;
+        if (lds > 48 * 1024)
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(assignment_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    WT_TRY(dc.alloc(4 * in_elems)); WT_TRY(dw.alloc(in_lds ? 16 : 4 * elems)); WT_TRY(dp.alloc(8 * (size_t)small)); WT_TRY(dr.alloc(16));
+    WT_HIP(hipMemcpy(dc.p, cost, 4 * in_elems, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(assignment_kernel, dim3(1), dim3(kWave), (in_lds ? wt::align_up(4 * elems, 16) : 0) + mk, nullptr, dc.as<float>(),
                        n_rows, n_cols, dw.as<float>(), dp.as<int>(), dr.as<int>(), in_lds);
     WT_HIP(hipGetLastError());
     WT_HIP(hipDeviceSynchronize());
@@ -389,8 +389,8 @@ int wt_associate_host(const float* dets5, int n, const double* trks4, int t, dou
     *n_matches = 0; *n_unmatched_dets = 0; *n_unmatched_trks = 0;
     WT_TRY(wt::ensure_device());
     if (n == 0 && t == 0) return WT_OK;
-    const size_t elems = (size_t)n * (size_t)t;
     const int small = n < t ? n : t, big = n < t ? t : n;
+    const size_t elems = (size_t)(small > 0 ? small : 1) * (size_t)((big > 0 ? big : 1) | 1);
     const size_t mk = munkres_lds_bytes(small > 0 ? small : 1, big > 0 ? big : 1);
     if (mk > kLdsMunkresMax) { wt::set_error("assignment of %d x %d exceeds the LDS budget", n, t); return WT_ERR_CAPACITY; }
     const bool in_lds = elems <= (size_t)kLdsCostFloats;
@@ -398,9 +398,15 @@ int wt_associate_host(const float* dets5, int n, const double* trks4, int t, dou
     WT_TRY(dd.alloc(20 * (size_t)n)); WT_TRY(dt.alloc(32 * (size_t)t)); WT_TRY(dw.alloc(in_lds ? 16 : 4 * elems));
     WT_TRY(dm.alloc(4 * (size_t)n)); WT_TRY(df.alloc(4 * (size_t)t)); WT_TRY(dma.alloc(8 * (size_t)(small + 1)));
     WT_TRY(dud.alloc(4 * (size_t)(n + 1))); WT_TRY(dut.alloc(4 * (size_t)(t + 1))); WT_TRY(dr.alloc(16));
+    {
+        const size_t lds = (in_lds ? wt::align_up(4 * elems, 16) : 0) + mk;
+        if (lds > 48 * 1024)
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(associate_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (n) WT_HIP(hipMemcpy(dd.p, dets5, 20 * (size_t)n, hipMemcpyHostToDevice));
     if (t) WT_HIP(hipMemcpy(dt.p, trks4, 32 * (size_t)t, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(associate_kernel, dim3(1), dim3(kWave), (in_lds ? 4 * elems : 0) + mk, nullptr, dd.as<float>(), n,
+    hipLaunchKernelGGL(associate_kernel, dim3(1), dim3(kWave), (in_lds ? wt::align_up(4 * elems, 16) : 0) + mk, nullptr, dd.as<float>(), n,
                        dt.as<double>(), t, iou_threshold, dw.as<float>(), in_lds, dm.as<int>(), df.as<int>(),
                        dma.as<int>(), dud.as<int>(), dut.as<int>(), dr.as<int>());
     WT_HIP(hipGetLastError());

@@ -11,6 +11,11 @@ import torch
 from ... import _lib
 
 
+# bench.py sets this to a list to time every deformable-conv launch with HIP events recorded on the launch stream
+# (tag, flops, start_event, end_event); None = no instrumentation.
+EVENT_LOG = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -113,10 +118,19 @@ def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None
     wo = (w + 2 * pad - 3) // stride + 1
     assert offset is None or offset.shape == (n, 18, ho, wo), (offset.shape, (n, 18, ho, wo))
     y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    log = EVENT_LOG
+    if log is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.lib().wd_deform_conv3x3_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
                                                 C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
                                                 C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad), _p(y), _stream()),
                'wd_deform_conv3x3_f32')
+    if log is not None:
+        e1.record()
+        log.append(('deform_conv3x3 C=%d %dx%d s%d%s' % (c, ho, wo, stride, '' if offset is not None else ' (no offsets)'),
+                    2.0 * c * (c // groups) * 9 * ho * wo * n, e0, e1))
     return y
 
 
