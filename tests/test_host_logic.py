@@ -1,0 +1,68 @@
+"""CPU tests of host-side logic: wire formats, CLI parsers, synthetic generators (no GPU, no compute kernels)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def test_load_prediction_matches_reference_fixture(golden_dir):
+    """detection-JSON wire format (coco.py:229-252) against rows produced by the reference's own load_prediction."""
+    from waymo_2d_tracking_amd.detnet.inference import load_prediction
+    g = json.load(open(os.path.join(golden_dir, 'export_g6.json')))
+    sizes = {k: (v['width'], v['height']) for k, v in g['images'].items()}
+    preds = {k: [np.asarray(a, dtype=np.float32).reshape(-1, 5) for a in v] for k, v in g['predictions'].items()}
+    rows = load_prediction(sizes, g['classnames'], preds)
+    assert len(rows) == len(g['rows'])
+    for a, b in zip(rows, g['rows']):
+        assert (a['image_id'], a['category_id'], a['bbox']) == (b['image_id'], b['category_id'], b['bbox'])
+        assert abs(a['score'] - b['score']) <= 1.0000001e-5      # numpy-2 vs Python round on exact half-ways
+        assert all(isinstance(v, int) for v in a['bbox'])
+
+
+def test_track_cli_flags_match_reference():
+    from waymo_2d_tracking_amd.tracking.track import build_parser
+    a = build_parser().parse_args([])
+    assert a.max_age == 1 and a.min_hits == 0                                   # track.py:21-22
+    assert a.score_threshold == [0.95, 0.6, 1.0, 0.9] and a.iou_threshold == [0.01, 0.01, 1.0, 0.0]   # :23-26
+    b = build_parser().parse_args(['--input', 'x.json', '--output', 'y.json', '--max-age=2', '--min-hits=0',
+                                   '--score-threshold=0.95,0.6,1.0,0.9', '--segment-id', 's', '--ground-truth', 'nofile'])
+    assert b.max_age == 2 and b.segment_id == 's'
+
+
+def test_ensemble_cli_refuses_existing_output_and_parses(tmp_path, golden_dir):
+    from waymo_2d_tracking_amd.detnet import ensemble as E
+    out = tmp_path / 'exists.json'
+    out.write_text('[]')
+    with pytest.raises(RuntimeError):                                           # ensemble.py:131-132
+        E.main([os.path.join(golden_dir, 'ensemble_g2_input0.json'), os.path.join(golden_dir, 'ensemble_g2_input1.json'),
+                '-o', str(out), '-m', 'soft_nms'])
+    subs = [json.load(open(os.path.join(golden_dir, 'ensemble_g2_input%d.json' % i))) for i in range(2)]
+    dets = [E.convert_submission(s, 1.0, 0.01) for s in subs]
+    packed = E.pack_groups(sorted(dets[0].keys()), [1, 2, 4], dets)
+    assert packed['group_offsets'][-1] == len(packed['dets5'])
+    assert packed['input_sizes'].shape == (len(packed['keys']), 2)
+    assert packed['input_sizes'].sum() == len(packed['dets5'])
+
+
+def test_yaml_weights_loader():
+    from waymo_2d_tracking_amd.detnet.ensemble import load_yml_input_and_weight
+    got = load_yml_input_and_weight({'a': {'x.json': 1, 'y.json': 0.5}, 'b.json': 2})     # ensemble.py:67-75
+    assert got == [('a/x.json', 1), ('a/y.json', 0.5), ('b.json', 2)]
+
+
+def test_synthetic_streams_shape():
+    from waymo_2d_tracking_amd import synthetic as syn
+    dets = syn.make_sequence_json(0, n_segments=1, n_frames=10, n_objects=100)
+    per_frame = len(dets) / (10 * 5)
+    assert 80 < per_frame < 120                                                 # ~100 boxes/frame
+    assert set(d['category_id'] for d in dets) <= {1, 2, 4}
+    assert all(isinstance(v, int) for v in dets[0]['bbox'])
+    seg, ts, cam = dets[0]['image_id'].split('/')
+    assert cam in syn.CAMERAS and int(ts) > 0
+
+
+def test_inference_cli_flags():
+    from waymo_2d_tracking_amd.detnet.inference import build_parser
+    a = build_parser().parse_args(['-i', 'imgs', '--export', 's.json', '--tta', 'x1.5,hflip', '--batch-size=1', '-j', '8'])
+    assert a.tta == 'x1.5,hflip' and a.export == 's.json' and a.threshold == 0.01

@@ -130,40 +130,5 @@ def run(args, world, rank, timed_steps):
                         % ('SORT (max_age 2, min_hits 0, all boxes tracked)' if track else 'no tracking', 5, fps),
                roofline=roofline,
                extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births))
-    if rank == 0 and not args.no_cpu_baseline:
-        res['cpu_baseline'] = cpu_baseline(pipe, track)
+    res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters
     return res, steps, warmup
-
-
-def cpu_baseline(pipe, track, height=448, width=640):
-    """The CPU restatement of the same path (oracle/detector_ref.py + oracle/sort_oracle.c) on the host cores, on a
-    bounded sample: ONE synthetic frame at 640x448 (1/8.23 of the 1920x1280 pixels; the 1000-proposal cascade
-    heads are resolution independent) followed by SORT on its detections.  value = measured frames/s at that size;
-    `full_res_equivalent` divides the backbone share by the pixel ratio."""
-    import copy
-    from oracle import detector_ref as R
-    from oracle import oracle as O
-    O.build()
-    cpu = copy.deepcopy(pipe.model.model).cpu()
-    g = torch.Generator().manual_seed(0)
-    img = torch.randint(0, 256, (1, 3, height, width), generator=g).float()[:, [2, 1, 0]]
-    t0 = time.perf_counter()
-    boxes, scores, classes = R.forward(cpu, img)
-    t_det = time.perf_counter() - t0
-    t_sort = 0.0
-    if track:
-        xywh, score, cat = detections_to_wire(boxes, scores, classes, width, height)
-        n = xywh.shape[0]
-        packed = dict(x=xywh[:, 0].numpy().copy(), y=xywh[:, 1].numpy().copy(), w=xywh[:, 2].numpy().copy(),
-                      h=xywh[:, 3].numpy().copy(), score=score.numpy().copy(), category=cat.numpy().astype(np.int32),
-                      frame_det_offsets=np.array([0, n], np.int64), stream_frame_offsets=np.array([0, 1], np.int64),
-                      clip_w=np.array([float(width)]), clip_h=np.array([float(height)]))
-        t0 = time.perf_counter()
-        O.track_streams(packed, 2, 0, [0.0] * 4, [0.01, 0.01, 1.0, 0.0])
-        t_sort = time.perf_counter() - t0
-    ratio = (1920 * 1280) / float(height * width)
-    return dict(value=1.0 / (t_det + t_sort), unit='frames/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 synthetic frame at %dx%d through oracle/detector_ref.py (PyTorch CPU fp32, same parameters) + '
-                       'oracle SORT: detector %.2f s, SORT %.4f s; 1920x1280 has %.2fx the pixels'
-                       % (width, height, t_det, t_sort, ratio),
-                full_res_equivalent=1.0 / (t_det * ratio + t_sort))

@@ -11,6 +11,8 @@ import argparse
 import json
 import time
 
+import os
+
 from .utils import read_data_file, track_all
 
 
@@ -41,13 +43,30 @@ def main(argv=None):
     predictions = read_data_file(args.input, args.score_threshold)
     if args.segment_id:
         predictions = {k: v for k, v in predictions.items() if k in [args.segment_id]}
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:                                  # torchrun: one process per GPU, streams sharded (distributed.py)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group('nccl')
     start_time = time.time()
-    for segment_id in predictions.keys():
-        print(segment_id)
-    tracked_predictions = track_all(predictions, args.iou_threshold, args.max_age, args.min_hits)
-    print("duration: %.2fs" % (time.time() - start_time))
-    with open(args.output, 'wt') as fp:
-        json.dump(tracked_predictions, fp)
+    if rank == 0:
+        for segment_id in predictions.keys():
+            print(segment_id)
+    if world > 1:
+        from ..distributed import track_all_sharded
+        tracked_predictions, _ = track_all_sharded(predictions, args.iou_threshold, args.max_age, args.min_hits)
+    else:
+        tracked_predictions = track_all(predictions, args.iou_threshold, args.max_age, args.min_hits)
+    if rank == 0:
+        print("duration: %.2fs" % (time.time() - start_time))
+        with open(args.output, 'wt') as fp:
+            json.dump(tracked_predictions, fp)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 
