@@ -4,8 +4,16 @@
 //
 // Layout: features NHWC, so the 64 lanes of a wavefront read 64 consecutive channels (256 B) of one feature
 // pixel per load; bilinear weights and sample coordinates are wave-uniform.  One workgroup (4 waves) per ROI:
-// wave w owns channels [64w, 64w+64) (+256 strides) and walks the 7x7 bins; each output element is written once,
-// coalesced.  Algorithmic bytes per ROI: unique footprint (h_f+1)(w_f+1)*C*4 + 20 B roi + 49*C*4 B out.
+// wave w owns channels [64w, 64w+64) (+256 strides); each output element is written once, coalesced.
+// Algorithmic bytes per ROI: unique footprint (h_f+1)(w_f+1)*C*4 + 20 B roi + 49*C*4 B out.
+//
+// Main kernel (roi_pool_sep_kernel): average pooling of bilinear samples is SEPARABLE - a bin's value is
+//   sum_r sum_q WY[ph][r] * WX[pw][q] * f[r][q] / count,   WY / WX = per-axis sums of the bilinear weights of the
+// bin's samples.  The two small weight tables are built once per ROI in LDS; per bin row the wave makes ONE pass
+// over the footprint rows it touches (t[q] = sum_r WY[ph][r] f[r][q], a handful of independent coalesced loads per
+// column, 16 in flight per lane) and folds each column sum into the 7 bins.  Every footprint pixel is read ~1.5x instead
+// of 4*g*g/(g+1)^2 ... times, with >= 12 loads in flight per lane.  ROIs wider/taller than 64 feature pixels on
+// their level fall back to the direct kernel below (roi_pool_fpn_kernel).
 #include "common.h"
 #include "../../include/waymodet.h"
 
@@ -23,8 +31,9 @@ struct Levels {
 __global__ __launch_bounds__(256) void roi_pool_fpn_kernel(Levels lv, int n_levels, int C, int batch,
                                                            const float* __restrict__ rois, int n_rois, int P,
                                                            int min_level, int canonical_level, float canonical_size,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const int* __restrict__ only_flagged) {
     const int r = blockIdx.x;
+    if (only_flagged && !only_flagged[r]) return;         // already done by the separable kernel
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const float* roi = rois + 5 * (size_t)r;
@@ -105,6 +114,125 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_kernel(Levels lv, int n_leve
     }
 }
 
+constexpr int kMaxFoot = 64;      // footprint rows / columns handled by the separable kernel (larger: direct kernel)
+
+__global__ __launch_bounds__(256) void roi_pool_sep_kernel(Levels lv, int n_levels, int C, int batch,
+                                                           const float* __restrict__ rois, int n_rois, int P,
+                                                           int min_level, int canonical_level, float canonical_size,
+                                                           float* __restrict__ out, int* __restrict__ fallback_flags) {
+    __shared__ float wy[7][kMaxFoot];
+    __shared__ float wx[7][kMaxFoot];
+    __shared__ int lo_hi[2][7][2];          // [axis][bin][first, last] non-zero index
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const float* roi = rois + 5 * (size_t)r;
+    const int b = (int)roi[0];
+    const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+    const float size = sqrtf((x2 - x1) * (y2 - y1));
+    int lvl = (int)floorf((float)canonical_level + log2f(size / canonical_size + 1e-8f));
+    lvl = lvl < min_level ? min_level : (lvl > min_level + n_levels - 1 ? min_level + n_levels - 1 : lvl);
+    const int li = lvl - min_level;
+    const int H = lv.h[li], W = lv.w[li];
+    const float scale = lv.scale[li];
+    if (fallback_flags && threadIdx.x == 0) fallback_flags[r] = 0;
+    if (b < 0 || b >= batch) {
+        for (int i = threadIdx.x; i < P * P * C; i += 256) out[(size_t)r * P * P * C + i] = 0.f;
+        return;
+    }
+    const float* __restrict__ feat = lv.feat[li] + (size_t)b * H * W * C;
+    const float rsw = x1 * scale - 0.5f, rsh = y1 * scale - 0.5f;
+    const float rew = x2 * scale - 0.5f, reh = y2 * scale - 0.5f;
+    const float roi_w = rew - rsw, roi_h = reh - rsh;
+    const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
+    const int gh = (int)ceilf(roi_h / (float)P), gw = (int)ceilf(roi_w / (float)P);
+    const float count = (float)((gh * gw) > 1 ? gh * gw : 1);
+    // footprint origin = the low corner of the first sample (after the ROIAlign clamps)
+    auto low_index = [](float v, int n) {
+        if (v <= 0) v = 0;
+        int l = (int)v;
+        return l >= n - 1 ? n - 1 : l;
+    };
+    const int r_lo = low_index(rsh + .5f * bin_h / (float)(gh > 0 ? gh : 1), H);
+    const int q_lo = low_index(rsw + .5f * bin_w / (float)(gw > 0 ? gw : 1), W);
+    const float y_last = rsh + (float)(P - 1) * bin_h + ((float)(gh > 0 ? gh - 1 : 0) + .5f) * bin_h / (float)(gh > 0 ? gh : 1);
+    const float x_last = rsw + (float)(P - 1) * bin_w + ((float)(gw > 0 ? gw - 1 : 0) + .5f) * bin_w / (float)(gw > 0 ? gw : 1);
+    const int r_hi = low_index(y_last, H) + 1 < H ? low_index(y_last, H) + 1 : H - 1;
+    const int q_hi = low_index(x_last, W) + 1 < W ? low_index(x_last, W) + 1 : W - 1;
+    const int nrows = r_hi - r_lo + 1, ncols = q_hi - q_lo + 1;
+    if (P != 7 || nrows > kMaxFoot || ncols > kMaxFoot || nrows < 1 || ncols < 1) {      // rare: direct kernel does it
+        if (fallback_flags && threadIdx.x == 0) fallback_flags[r] = 1;
+        return;
+    }
+    // ---- per-axis weight tables (thread ph builds row ph sequentially: deterministic sums) ----
+    for (int i = threadIdx.x; i < 7 * kMaxFoot; i += 256) { (&wy[0][0])[i] = 0.f; (&wx[0][0])[i] = 0.f; }
+    __syncthreads();
+    if (threadIdx.x < 14) {
+        const int axis = threadIdx.x / 7, p = threadIdx.x % 7;
+        const int g = axis ? gw : gh, N = axis ? W : H, lo = axis ? q_lo : r_lo;
+        const float start = axis ? rsw : rsh, bin = axis ? bin_w : bin_h;
+        float* wrow = axis ? wx[p] : wy[p];
+        int first = kMaxFoot, last = -1;
+        for (int i = 0; i < g; ++i) {
+            float v = start + (float)p * bin + ((float)i + .5f) * bin / (float)g;
+            if (v < -1.0f || v > (float)N) continue;
+            if (v <= 0) v = 0;
+            int l = (int)v, h;
+            if (l >= N - 1) { h = l = N - 1; v = (float)l; } else h = l + 1;
+            const float fl = v - (float)l;
+            wrow[l - lo] += 1.f - fl;
+            wrow[h - lo] += fl;
+            first = (l - lo) < first ? (l - lo) : first;
+            last = (h - lo) > last ? (h - lo) : last;
+        }
+        lo_hi[axis][p][0] = first;
+        lo_hi[axis][p][1] = last;
+    }
+    __syncthreads();
+    for (int cb = wave * 64; cb < C; cb += 256) {
+        const int c = cb + lane;
+        const bool cok = c < C;
+        const float* __restrict__ fc = feat + ((size_t)r_lo * W + q_lo) * C + (cok ? c : 0);
+        for (int ph = 0; ph < 7; ++ph) {
+            const int ra = lo_hi[0][ph][0], rb = lo_hi[0][ph][1];
+            float bins[7];
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) bins[pw] = 0.f;
+            // row pass over 8 columns x 2 rows at a time (16 independent coalesced loads in flight per lane); each
+            // column sum t = sum_r WY[ph][r] f[r][q] is folded straight into the 7 bins with WX[pw][q]
+            for (int q0 = 0; q0 < ncols; q0 += 8) {
+                float acc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+                for (int rr = ra; rr <= rb; rr += 2) {
+                    const int r1 = (rr + 1 <= rb) ? rr + 1 : rb;
+                    const float w0 = wy[ph][rr], w1 = (rr + 1 <= rb) ? wy[ph][r1] : 0.f;
+                    float v0[8], v1[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int qq = (q0 + u < ncols) ? q0 + u : ncols - 1;
+                        v0[u] = fc[((size_t)rr * W + qq) * C];
+                        v1[u] = fc[((size_t)r1 * W + qq) * C];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[u] += w0 * v0[u] + w1 * v1[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int qq = (q0 + u < ncols) ? q0 + u : ncols - 1;
+                    const float tv = (q0 + u < ncols) ? acc[u] : 0.f;
+#pragma unroll
+                    for (int pw = 0; pw < 7; ++pw) bins[pw] += wx[pw][qq] * tv;
+                }
+            }
+            if (cok) {
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) out[(((size_t)r * 7 + ph) * 7 + pw) * C + c] = bins[pw] / count;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* heights, const int32_t* widths,
@@ -119,8 +247,26 @@ extern "C" int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* hei
     if (n_rois <= 0) return WT_OK;
     Levels lv;
     for (int i = 0; i < n_levels; ++i) { lv.feat[i] = feats[i]; lv.h[i] = heights[i]; lv.w[i] = widths[i]; lv.scale[i] = scales[i]; }
-    hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
-                       channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out);
+    // The separable kernel handles ROIs whose footprint fits 64 x 64 feature pixels (all but degenerate whole-image
+    // boxes); it flags the rest, which the direct kernel then processes (it exits immediately for unflagged ROIs).
+    static thread_local int* flags = nullptr;
+    static thread_local int flags_cap = 0;
+    if (pooled == 7) {
+        if (flags_cap < n_rois) {
+            if (flags) (void)hipFree(flags);
+            WT_HIP(hipMalloc(&flags, sizeof(int) * (size_t)n_rois * 2));
+            flags_cap = n_rois * 2;
+        }
+        hipLaunchKernelGGL(roi_pool_sep_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
+                           channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out, flags);
+        hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
+                           channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out,
+                           (const int*)flags);
+    } else {
+        hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
+                           channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out,
+                           (const int*)nullptr);
+    }
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
