@@ -7,6 +7,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* torch.sort semantics for NaN: NaN is the largest value (sorted last in ascending order) */
+static int gt_nan_last(double a, double b)
+{
+    const int an = a != a, bn = b != b;
+    if (an || bn) return an && !bn;
+    return a > b;
+}
+
 /* stable ascending argsort (scores.sort(0), box_utils.py:324; tie order is unspecified upstream - stable here) */
 static void argsort_ascending(const double* v, int n, int64_t* idx)
 {
@@ -16,7 +24,7 @@ static void argsort_ascending(const double* v, int n, int64_t* idx)
     if (n < 64) {
         for (i = 1; i < n; ++i) {
             int64_t k = idx[i];
-            for (j = i - 1; j >= 0 && v[idx[j]] > v[k]; --j) idx[j + 1] = idx[j];
+            for (j = i - 1; j >= 0 && gt_nan_last(v[idx[j]], v[k]); --j) idx[j + 1] = idx[j];
             idx[j + 1] = k;
         }
         return;
@@ -28,7 +36,7 @@ static void argsort_ascending(const double* v, int n, int64_t* idx)
         for (i = 0; i < n; i += 2 * width) {
             int a = i, b = i + width < n ? i + width : n, e = i + 2 * width < n ? i + 2 * width : n;
             int p = a, q = b, o = a;
-            while (p < b && q < e) tmp[o++] = (v[idx[q]] < v[idx[p]]) ? idx[q++] : idx[p++];
+            while (p < b && q < e) tmp[o++] = gt_nan_last(v[idx[p]], v[idx[q]]) ? idx[q++] : idx[p++];
             while (p < b) tmp[o++] = idx[p++];
             while (q < e) tmp[o++] = idx[q++];
         }

@@ -132,3 +132,35 @@ def test_full_size_properties():
         assert np.all(res[:, 0] <= src[order, 0] + 0)               # scores only decay
         assert res[0, 0] == src[order[0], 0]                        # the top box is untouched
         np.testing.assert_allclose(res[:, 3:5], src[order, 3:5], rtol=1e-12)   # geometry is preserved, in rank order
+
+
+def test_soft_nms_groups_with_nan_negative_and_degenerate_boxes(oracle):
+    """Groups the dependency-free kernel must hand to the serial one (NaN / negative scores), zero-area boxes,
+    duplicates and exact score ties - all still bit-identical to the oracle."""
+    import ctypes as C
+    from waymo_2d_tracking_amd import _lib
+    from waymo_2d_tracking_amd import synthetic as syn
+    rng = np.random.default_rng(31)
+    rows, off = [], [0]
+    for g in range(12):
+        gs = np.concatenate(syn.ensemble_group(rng, 30, 3))
+        if g % 4 == 0:
+            gs[5, 0] = np.nan
+        if g % 4 == 1:
+            gs[7, 0] = -0.25
+        if g % 4 == 2:
+            gs[3, 3] = 0.0                      # zero width
+            gs[9] = gs[8]                       # exact duplicate (score tie, IoU 1)
+        rows.append(gs); off.append(off[-1] + len(gs))
+    d = np.ascontiguousarray(np.vstack(rows)); off = np.asarray(off, np.int64)
+    sizes = np.full((12, 3), 30, np.int32)
+    for cut in (0.9, 1.0):
+        exp, exp_cnt = oracle.ensemble_groups(d, off, sizes, 3, 2, 0.5, cut)
+        out = np.zeros((len(d) + 1, 5)); cnt = np.zeros(13, np.int64)
+        _lib.check(_lib.lib().wt_ensemble_groups_host(_lib.ptr(d), _lib.ptr(off), _lib.ptr(sizes), C.c_int64(12), C.c_int(3),
+                                                      C.c_int(2), C.c_double(0.5), C.c_double(cut), _lib.ptr(out), _lib.ptr(cnt)),
+                   'wt_ensemble_groups_host')
+        assert np.array_equal(cnt[:12], exp_cnt)
+        for g in range(12):
+            a, b = int(off[g]), int(off[g]) + int(exp_cnt[g])
+            assert np.array_equal(out[a:b], exp[a:b], equal_nan=True), g

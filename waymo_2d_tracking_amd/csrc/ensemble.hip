@@ -277,13 +277,154 @@ __device__ void ensemble_fusion_group(const double* __restrict__ in, int n, cons
     if (lane == 0) *out_count = m;
 }
 
+
+// ---- dependency-free soft-NMS (ensemble path: conf_thresh == 0, 0 <= thr < cut) ---------------------------------
+// With conf_thresh = 0 a box only leaves the list when its score turns NaN / negative, so for finite non-negative
+// scores every box survives and the decay of box j is just the product, in rank order, of the weights of the boxes
+// ranked above it - the weights depend on geometry only.  That removes the per-rank barrier of the serial loop:
+//   * 256 threads per group rank the boxes by counting and rewrite them in rank order in LDS (killers, read-only);
+//   * victims are walked in x-sorted order, 64 per wavefront, so that a killer overlaps either several lanes of a
+//     wave or none: the cheap interval test + one ballot skips the two float64 divisions for most (killer, chunk)
+//     pairs (a non-overlapping pair has weight clamp(cut/(cut-thr)) == 1 exactly, so skipping is bit-exact);
+//   * no synchronisation inside the main loop.
+// Groups with NaN / negative scores, thr < 0 or conf_thresh > 0 are flagged and handled by the serial kernel.
+constexpr int kFastThreads = 256;
+constexpr int kFastMaxPerThread = 8;             // n <= 2048
+
+__host__ __device__ inline size_t fast_mem_bytes(size_t cap) { return cap * (6 * sizeof(double) + sizeof(int)) + 32; }
+
+__global__ __launch_bounds__(kFastThreads) void softnms_fast_kernel(
+    const double* __restrict__ dets5, const int64_t* __restrict__ group_offsets, int64_t n_groups, int centre,
+    double thr, double cut, double* __restrict__ out5, int64_t* __restrict__ out_counts, int* __restrict__ fallback,
+    size_t cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ks = reinterpret_cast<double*>(smem);        // by rank: score, x1, y1, x2, y2, area
+    double* kx1 = ks + cap; double* ky1 = ks + 2 * cap; double* kx2 = ks + 3 * cap; double* ky2 = ks + 4 * cap;
+    double* kar = ks + 5 * cap;
+    int* vord = reinterpret_cast<int*>(ks + 6 * cap);    // victims in x order -> rank index
+    int& bad = vord[cap];                                // (kept inside the dynamic block: its base stays 16-B aligned)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t o0 = group_offsets[g];
+        const int n = (int)(group_offsets[g + 1] - o0);
+        if (tid == 0) bad = 0;
+        __syncthreads();
+        if (n == 0) { if (tid == 0) { out_counts[g] = 0; fallback[g] = 0; } continue; }
+        if (n > kFastThreads * kFastMaxPerThread || (size_t)n > cap) { if (tid == 0) fallback[g] = 1; continue; }
+        const double* in = dets5 + 5 * o0;
+        // 1. coalesced load, AoS -> SoA (raw order) into the LDS arrays
+        double* col[5] = {ks, kx1, ky1, kx2, ky2};
+        for (int j = tid; j < 5 * n; j += kFastThreads) { const int r = j / 5, c = j - 5 * r; col[c][r] = in[j]; }
+        __syncthreads();
+        // 2. corners per owned box (registers), validity check, rank by counting
+        double bs[kFastMaxPerThread], b1[kFastMaxPerThread], b2[kFastMaxPerThread], b3[kFastMaxPerThread], b4[kFastMaxPerThread];
+        int rk[kFastMaxPerThread];
+        bool mybad = false;
+#pragma unroll
+        for (int k = 0; k < kFastMaxPerThread; ++k) {
+            const int i = tid + k * kFastThreads;
+            rk[k] = -1;
+            if (i < n) {
+                const double sc = ks[i], x = kx1[i], y = ky1[i], w = kx2[i], h = ky2[i];
+                const double cx = centre ? x : x + w / 2, cy = centre ? y : y + h / 2;
+                const double hx = w * 0.5, hy = h * 0.5;
+                bs[k] = sc; b1[k] = cx - hx; b2[k] = cy - hy; b3[k] = cx + hx; b4[k] = cy + hy;
+                mybad = mybad || !(sc >= 0.) || !(sc - sc == 0.);
+                int cnt = 0;
+                for (int j = 0; j < n; ++j) cnt += before(ks[j], j, sc, i) ? 1 : 0;
+                rk[k] = cnt;
+            }
+        }
+        if (mybad) bad = 1;
+        __syncthreads();
+        if (bad) { if (tid == 0) fallback[g] = 1; __syncthreads(); continue; }
+        // 3. rewrite in rank order (all reads of the raw arrays are done)
+#pragma unroll
+        for (int k = 0; k < kFastMaxPerThread; ++k)
+            if (rk[k] >= 0) {
+                const int r = rk[k];
+                ks[r] = bs[k]; kx1[r] = b1[k]; ky1[r] = b2[k]; kx2[r] = b3[k]; ky2[r] = b4[k];
+                kar[r] = (b3[k] - b1[k]) * (b4[k] - b2[k]);
+            }
+        __syncthreads();
+        // 4. x order of the victims (count-rank on (x1, rank))
+        for (int r = tid; r < n; r += kFastThreads) {
+            const double xr = kx1[r];
+            int cnt = 0;
+            for (int j = 0; j < n; ++j) { const double xj = kx1[j]; cnt += (xj < xr || (xj == xr && j < r)) ? 1 : 0; }
+            vord[cnt] = r;
+        }
+        __syncthreads();
+        // 5. decay: each wave owns x-sorted chunks of 64 victims; killers walked in rank order
+        for (int base = wave * 64; base < n; base += (kFastThreads / 64) * 64) {
+            const int v = base + lane;
+            const bool act = v < n;
+            const int myr = act ? vord[v] : 0;
+            const double mx1 = kx1[myr], my1 = ky1[myr], mx2 = kx2[myr], my2 = ky2[myr], mar = kar[myr];
+            double ms = ks[myr];
+            // x extent of the chunk: killers that cannot reach it are skipped with one scalar compare
+            double cmin = act ? mx1 : 1e300, cmax = act ? mx2 : -1e300;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double a = __shfl_xor(cmin, o, 64), b = __shfl_xor(cmax, o, 64);
+                cmin = a < cmin ? a : cmin; cmax = b > cmax ? b : cmax;
+            }
+            int rmax = act ? myr : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_xor(rmax, o, 64); rmax = a > rmax ? a : rmax; }
+            for (int r = 0; r < rmax; ++r) {
+                const double bx1 = kx1[r], bx2 = kx2[r];
+                if (!(bx2 > cmin && bx1 < cmax)) continue;                 // wave-uniform: no overlap in x
+                const double by1 = ky1[r], by2 = ky2[r];
+                double xx1 = mx1; if (xx1 < bx1) xx1 = bx1;
+                double yy1 = my1; if (yy1 < by1) yy1 = by1;
+                double xx2 = mx2; if (xx2 > bx2) xx2 = bx2;
+                double yy2 = my2; if (yy2 > by2) yy2 = by2;
+                double w = xx2 - xx1; if (w < 0.) w = 0.;
+                double h = yy2 - yy1; if (h < 0.) h = 0.;
+                const double inter = w * h;
+                const bool hit = act && r < myr && inter > 0.;
+                if (__ballot(hit) == 0ull) continue;
+                if (hit) {
+                    const double uni = (mar - inter) + kar[r];
+                    const double iou = inter / uni;
+                    double wgt = (cut - iou) / (cut - thr);
+                    wgt = wgt < 0. ? 0. : (wgt > 1. ? 1. : wgt);
+                    ms = ms * wgt;
+                }
+            }
+            if (act) ks[myr] = ms;                                           // each rank slot is owned by one lane
+        }
+        __syncthreads();
+        // 6. output in rank order (every box survives)
+        double* out = out5 + 5 * o0;
+        for (int j = tid; j < 5 * n; j += kFastThreads) {
+            const int k = j / 5, c = j - 5 * k;
+            double v;
+            if (c == 0) v = ks[k];
+            else if (c == 1 || c == 3) {
+                const double wd = kx2[k] - kx1[k], cxo = (kx1[k] + kx2[k]) * 0.5;
+                v = (c == 3) ? wd : (centre ? cxo : cxo - wd / 2);
+            } else {
+                const double hd = ky2[k] - ky1[k], cyo = (ky1[k] + ky2[k]) * 0.5;
+                v = (c == 4) ? hd : (centre ? cyo : cyo - hd / 2);
+            }
+            out[j] = v;
+        }
+        if (tid == 0) { out_counts[g] = n; fallback[g] = 0; }
+        __syncthreads();
+    }
+}
+
 template <bool kLds>
 __global__ __launch_bounds__(kWave) void ensemble_groups_kernel(
     const double* __restrict__ dets5, const int64_t* __restrict__ group_offsets,
     const int32_t* __restrict__ input_sizes, int64_t n_groups, int k_inputs, int method, double thr, double cut,
-    double* __restrict__ out5, int64_t* __restrict__ out_counts, char* scratch, size_t lds_cap, size_t bytes_per_row) {
+    double* __restrict__ out5, int64_t* __restrict__ out_counts, char* scratch, size_t lds_cap, size_t bytes_per_row,
+    const int* __restrict__ only_flagged) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        if (only_flagged && !only_flagged[g]) continue;        // done by softnms_fast_kernel
         const int64_t o0 = group_offsets[g];
         const int n = (int)(group_offsets[g + 1] - o0);
         if (n == 0) {
@@ -345,10 +486,29 @@ int launch_groups(const double* dets5, const int64_t* group_offsets, const int32
     const size_t cap = (size_t)(max_group_rows > 0 ? max_group_rows : 1);
     const size_t lds = mth == 0 ? fuse_mem_bytes(cap) : group_mem_bytes(cap);
     const int64_t grid = n_groups < (1 << 20) ? n_groups : (1 << 20);
+    // soft-NMS fast path (dependency-free form); it flags the groups it cannot take for the serial kernel below
+    const int* flags = nullptr;
+    if (mth == 2 && thr >= 0. && cut > thr && cap <= (size_t)kFastThreads * kFastMaxPerThread &&
+        fast_mem_bytes(cap) <= 150 * 1024) {
+        static thread_local int* d_flags = nullptr;
+        static thread_local int64_t d_flags_cap = 0;
+        if (d_flags_cap < n_groups) {
+            if (d_flags) (void)hipFree(d_flags);
+            WT_HIP(hipMalloc(&d_flags, sizeof(int) * (size_t)n_groups * 2));
+            d_flags_cap = n_groups * 2;
+        }
+        const size_t fl = fast_mem_bytes(cap);
+        if (fl > 48 * 1024)
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softnms_fast_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));
+        hipLaunchKernelGGL(softnms_fast_kernel, dim3((unsigned)grid), dim3(kFastThreads), fl, stream, dets5, group_offsets,
+                           n_groups, (method & 16) ? 1 : 0, thr, cut, out5, out_counts, d_flags, cap);
+        flags = d_flags;
+    }
     if (lds <= kLdsBudget) {
         hipLaunchKernelGGL(ensemble_groups_kernel<true>, dim3((unsigned)grid), dim3(kWave), lds, stream, dets5,
                            group_offsets, input_sizes, n_groups, k_inputs, method, thr, cut, out5, out_counts,
-                           (char*)nullptr, cap, (size_t)0);
+                           (char*)nullptr, cap, (size_t)0, flags);
     } else {
         const size_t need = wt_ensemble_groups_workspace(n_rows, n_groups, max_group_rows);
         if (!workspace || workspace_bytes < need) {
@@ -358,7 +518,7 @@ int launch_groups(const double* dets5, const int64_t* group_offsets, const int32
         // per-row bytes are padded so that each group's slice stays 16-byte aligned for any n
         hipLaunchKernelGGL(ensemble_groups_kernel<false>, dim3((unsigned)grid), dim3(kWave), 0, stream, dets5,
                            group_offsets, input_sizes, n_groups, k_inputs, method, thr, cut, out5, out_counts,
-                           (char*)workspace, (size_t)0, (size_t)128);
+                           (char*)workspace, (size_t)0, (size_t)128, flags);
     }
     WT_HIP(hipGetLastError());
     return WT_OK;
