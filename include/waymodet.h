@@ -67,6 +67,21 @@ int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias, const flo
 int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const float* beta, int n, int hw, int c, int groups,
                                float eps, int relu, void* stream);
 
+/* ---- backward (training fwd+bwd) ---------------------------------------------------
+ * ROIPooler backward: grad_out (R, pooled, pooled, C) is scattered (+=) into grad_feats[l] (same shapes as the
+ * forward feats; the caller zero-initialises them).  grad_feats: HOST array of DEVICE pointers. */
+int wd_roi_pool_fpn_bwd_f32(float* const* grad_feats, const int32_t* heights, const int32_t* widths, const float* scales,
+                            int n_levels, int channels, int batch, const float* rois, int n_rois, int pooled, int min_level,
+                            int canonical_level, float canonical_size, const float* grad_out, void* stream);
+/* Deformable conv backward building blocks (detectron2 deformable_im2col / col2im / col2im_coord restated):
+ *   im2col : col[p][k][c] (p = N*Ho*Wo output pixels, k = 9 taps, c = C_in, NHWC order) from x and offset;
+ *   col2im : dcol[p][k][c] -> dx (N,H,W,C) += and doffset (N,Ho,Wo,18) += (both zero-initialised by the caller).
+ * The weight / column GEMMs between them (dW = col^T dY, dcol = dY W^T per group) are plain library GEMMs. */
+int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, int w, int c, int stride, int pad, float* col,
+                         void* stream);
+int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int stride,
+                         int pad, float* dx, float* doffset, void* stream);
+
 /* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
 int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
 

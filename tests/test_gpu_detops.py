@@ -130,3 +130,49 @@ def test_groupnorm_relu_vs_torch():
     exp = torch.relu(torch.nn.functional.group_norm(x.double(), 32, w.double(), b.double(), 1e-5))
     got = ops.groupnorm_relu_(_cl(x), w.cuda(), b.cuda(), 32)
     np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_deform_conv_backward_vs_autograd_reference():
+    """dX, dOffset, dW of the HIP backward (im2col / GEMMs / col2im) vs torch autograd through the CPU restatement
+    (grid_sample based) in float64."""
+    from oracle import detector_ref as R
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    g = torch.Generator().manual_seed(21)
+    for C, stride, H, W in ((512, 1, 11, 13), (1024, 2, 12, 10)):
+        x = torch.randn((2, C, H, W), generator=g)
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        offset = torch.randn((2, 18, Ho, Wo), generator=g) * 1.3 + 0.37        # keep samples off integer coordinates
+        weight = torch.randn((C, C // 32, 3, 3), generator=g) / (3 * (C // 32) ** 0.5)
+        gy = torch.randn((2, C, Ho, Wo), generator=g)
+        xr, orf, wr = x.double().requires_grad_(), offset.double().requires_grad_(), weight.double().requires_grad_()
+        yr = R.deform_conv3x3(xr, orf, wr, 32, stride, 1)
+        yr.backward(gy.double())
+        xg = _cl(x).requires_grad_(); og = _cl(offset).requires_grad_(); wg = weight.cuda().requires_grad_()
+        yg = ops.DeformConvFn.apply(xg, og, wg, 32, stride, 1)
+        yg.backward(_cl(gy))
+        for name, a, b in (('dx', xg.grad, xr.grad), ('doffset', og.grad, orf.grad), ('dw', wg.grad, wr.grad)):
+            a, b = a.cpu().double(), b
+            err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+            assert err < 2e-4, (name, C, stride, err)
+
+
+def test_roi_pool_backward_vs_autograd_reference():
+    from oracle import detector_ref as R
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    g = torch.Generator().manual_seed(5)
+    strides = [4, 8, 16, 32]
+    feats = [torch.randn((1, 64, 96 // s, 128 // s), generator=g) for s in strides]
+    boxes = torch.tensor([[3.0, 5.0, 40.0, 33.0], [10.5, 2.25, 120.0, 90.0], [60.0, 40.0, 75.0, 58.0], [0.0, 0.0, 127.0, 95.0],
+                          [20.0, 30.0, 90.0, 44.0]])
+    gout = torch.randn((5, 64, 7, 7), generator=g)
+    fr = [f.double().requires_grad_() for f in feats]
+    out = R.roi_pool_fpn(fr, boxes, [1.0 / s for s in strides])
+    out.backward(gout.double())
+    fg = [_cl(f).requires_grad_() for f in feats]
+    rois = torch.cat((torch.zeros(5, 1), boxes), 1).cuda()
+    og = ops.RoiPoolFpnFn.apply(rois, [1.0 / s for s in strides], 7, 2, 4, 224.0, *fg)
+    og.backward(_cl(gout))
+    for l in range(4):
+        a = fg[l].grad.cpu().double()
+        b = fr[l].grad if fr[l].grad is not None else torch.zeros_like(a)      # level without ROIs
+        assert (a - b).abs().max().item() < 1e-4 * (b.abs().max().item() + 1e-6) + 1e-6, l

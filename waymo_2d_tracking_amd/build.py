@@ -30,6 +30,7 @@ UNITS = {
     'det_deform.hip': [],
     'det_gemm.hip': [],
     'det_misc.hip': [],
+    'det_backward.hip': ['-munsafe-fp-atomics'],
 }
 
 

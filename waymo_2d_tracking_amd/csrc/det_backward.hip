@@ -1,0 +1,230 @@
+// Backward kernels of the detector custom ops (training fwd+bwd), gfx950.
+//   * ROIAlign backward (detectron2 ROIAlign_backward restated): bilinear scatter of the bin gradients, lane = channel
+//     so every atomic batch touches 64 consecutive floats of one feature pixel;
+//   * deformable conv backward in the classic three-step form of the reference's CUDA op
+//     (deformable_im2col / deformable_col2im / deformable_col2im_coord): the im2col slab is materialised in HBM
+//     ([pixel][tap][channel], fully coalesced float4 stores), the two per-group GEMMs (dW, dcol) run on the library,
+//     and ONE fused scatter kernel turns dcol into dX (float atomics) and dOffset (wave-reduced, one atomic per wave).
+// Forward-speed kernels stay in det_deform.hip / det_roialign.hip; these favour simplicity and exactness.
+#include "common.h"
+#include "../../include/waymodet.h"
+
+namespace {
+
+constexpr int kMaxLevels = 8;
+struct LevelsW {
+    float* grad[kMaxLevels];
+    int h[kMaxLevels];
+    int w[kMaxLevels];
+    float scale[kMaxLevels];
+};
+
+__global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n_levels, int C, int batch,
+                                                               const float* __restrict__ rois, int P, int min_level,
+                                                               int canonical_level, float canonical_size,
+                                                               const float* __restrict__ gout) {
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* roi = rois + 5 * (size_t)r;
+    const int b = (int)roi[0];
+    if (b < 0 || b >= batch) return;
+    const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+    const float size = sqrtf((x2 - x1) * (y2 - y1));
+    int lvl = (int)floorf((float)canonical_level + log2f(size / canonical_size + 1e-8f));
+    lvl = lvl < min_level ? min_level : (lvl > min_level + n_levels - 1 ? min_level + n_levels - 1 : lvl);
+    const int li = lvl - min_level;
+    const int H = lv.h[li], W = lv.w[li];
+    const float scale = lv.scale[li];
+    float* __restrict__ grad = lv.grad[li] + (size_t)b * H * W * C;
+    const float rsw = x1 * scale - 0.5f, rsh = y1 * scale - 0.5f;
+    const float roi_w = (x2 * scale - 0.5f) - rsw, roi_h = (y2 * scale - 0.5f) - rsh;
+    const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
+    const int gh = (int)ceilf(roi_h / (float)P), gw = (int)ceilf(roi_w / (float)P);
+    const float count = (float)((gh * gw) > 1 ? gh * gw : 1);
+    for (int cb = wave * 64; cb < C; cb += 256) {
+        const int c = cb + lane;
+        if (c >= C) continue;
+        for (int ph = 0; ph < P; ++ph)
+            for (int pw = 0; pw < P; ++pw) {
+                const float g = gout[(((size_t)r * P + ph) * P + pw) * C + c] / count;
+                for (int iy = 0; iy < gh; ++iy) {
+                    float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                        float yy = y;
+                        if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+                        if (yy <= 0) yy = 0;
+                        if (x <= 0) x = 0;
+                        int yl = (int)yy, xl = (int)x, yh, xh;
+                        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+                        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                        const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                        atomicAdd(&grad[((size_t)yl * W + xl) * C + c], g * hy * hx);
+                        atomicAdd(&grad[((size_t)yl * W + xh) * C + c], g * hy * lx);
+                        atomicAdd(&grad[((size_t)yh * W + xl) * C + c], g * ly * hx);
+                        atomicAdd(&grad[((size_t)yh * W + xh) * C + c], g * ly * lx);
+                    }
+                }
+            }
+    }
+}
+
+struct Tap {
+    int idx[4];
+    float wgt[4];
+    float lh, lw;
+    int ok;          // sample inside (-1,H) x (-1,W)
+};
+
+__device__ __forceinline__ Tap make_tap(const float* __restrict__ offset, long gp, int k, int Ho, int Wo, int H, int W,
+                                        int stride, int pad) {
+    Tap t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { t.idx[q] = 0; t.wgt[q] = 0.f; }
+    t.lh = 0.f; t.lw = 0.f; t.ok = 0;
+    const int n = (int)(gp / ((long)Ho * Wo));
+    const int rem = (int)(gp - (long)n * Ho * Wo);
+    const int ho = rem / Wo, wo = rem - ho * Wo;
+    const int kh = k / 3, kw = k - 3 * kh;
+    const float h_im = (float)(ho * stride - pad + kh) + offset[(size_t)gp * 18 + 2 * k];
+    const float w_im = (float)(wo * stride - pad + kw) + offset[(size_t)gp * 18 + 2 * k + 1];
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+        const int hh = hl + 1, wh = wl + 1;
+        const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+        const int base = n * H * W;
+        t.lh = lh; t.lw = lw; t.ok = 1;
+        if (hl >= 0 && wl >= 0) { t.idx[0] = base + hl * W + wl; t.wgt[0] = (1.f - lh) * (1.f - lw); }
+        if (hl >= 0 && wh <= W - 1) { t.idx[1] = base + hl * W + wh; t.wgt[1] = (1.f - lh) * lw; }
+        if (hh <= H - 1 && wl >= 0) { t.idx[2] = base + hh * W + wl; t.wgt[2] = lh * (1.f - lw); }
+        if (hh <= H - 1 && wh <= W - 1) { t.idx[3] = base + hh * W + wh; t.wgt[3] = lh * lw; }
+        // validity flags for the coordinate gradient are encoded as idx >= 0 with wgt possibly 0: keep a bit set
+        t.ok |= (hl >= 0 && wl >= 0) ? 2 : 0;
+        t.ok |= (hl >= 0 && wh <= W - 1) ? 4 : 0;
+        t.ok |= (hh <= H - 1 && wl >= 0) ? 8 : 0;
+        t.ok |= (hh <= H - 1 && wh <= W - 1) ? 16 : 0;
+    }
+    return t;
+}
+
+// col[p][k][c] = bilinear(x, p, k, c)   (c fastest: float4 per thread, C/4 consecutive threads per (p, k))
+__global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                            long npix, int Ho, int Wo, int H, int W, int C, int stride,
+                                                            int pad, float* __restrict__ col) {
+    const int c4n = C >> 2;
+    const long total = npix * 9 * c4n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c4 = (int)(e % c4n);
+        const long pk = e / c4n;
+        const int k = (int)(pk % 9);
+        const long gp = pk / 9;
+        const Tap t = make_tap(offset, gp, k, Ho, Wo, H, W, stride, pad);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 s = *reinterpret_cast<const float4*>(x + (size_t)t.idx[q] * C + c4 * 4);
+            v.x += t.wgt[q] * s.x; v.y += t.wgt[q] * s.y; v.z += t.wgt[q] * s.z; v.w += t.wgt[q] * s.w;
+        }
+        *reinterpret_cast<float4*>(col + (size_t)e * 4) = v;
+    }
+}
+
+// dcol[p][k][c] -> dx (atomics) and doffset[p][2k], [2k+1] (reduced over channels: wave shuffle + one atomic per wave)
+__global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restrict__ dcol, const float* __restrict__ x,
+                                                            const float* __restrict__ offset, long npix, int Ho, int Wo,
+                                                            int H, int W, int C, int stride, int pad,
+                                                            float* __restrict__ dx, float* __restrict__ doffset) {
+    const int c4n = C >> 2;                       // a multiple of 32 (C % 128 == 0): a wave never straddles two (p, k)
+    const long total = npix * 9 * c4n;
+    for (long e0 = (long)blockIdx.x * 256; e0 < total; e0 += (long)gridDim.x * 256) {
+        const long e = e0 + threadIdx.x;
+        const bool act = e < total;
+        const long ee = act ? e : total - 1;
+        const int c4 = (int)(ee % c4n);
+        const long pk = ee / c4n;
+        const int k = (int)(pk % 9);
+        const long gp = pk / 9;
+        const Tap t = make_tap(offset, gp, k, Ho, Wo, H, W, stride, pad);
+        float4 g = act ? *reinterpret_cast<const float4*>(dcol + (size_t)ee * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = *reinterpret_cast<const float4*>(x + (size_t)t.idx[q] * C + c4 * 4);
+            if (!((t.ok >> (q + 1)) & 1)) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act && t.wgt[q] != 0.f) {
+                float* d = dx + (size_t)t.idx[q] * C + c4 * 4;
+                atomicAdd(d + 0, t.wgt[q] * g.x); atomicAdd(d + 1, t.wgt[q] * g.y);
+                atomicAdd(d + 2, t.wgt[q] * g.z); atomicAdd(d + 3, t.wgt[q] * g.w);
+            }
+        }
+        // d val / d h = (v3 - v1)(1 - lw) + (v4 - v2) lw ;  d val / d w = (v2 - v1)(1 - lh) + (v4 - v3) lh
+        float dh = 0.f, dw = 0.f;
+        if (t.ok & 1) {
+            const float a = 1.f - t.lw, b = t.lw, cc = 1.f - t.lh, d2 = t.lh;
+            dh = g.x * ((v[2].x - v[0].x) * a + (v[3].x - v[1].x) * b) + g.y * ((v[2].y - v[0].y) * a + (v[3].y - v[1].y) * b) +
+                 g.z * ((v[2].z - v[0].z) * a + (v[3].z - v[1].z) * b) + g.w * ((v[2].w - v[0].w) * a + (v[3].w - v[1].w) * b);
+            dw = g.x * ((v[1].x - v[0].x) * cc + (v[3].x - v[2].x) * d2) + g.y * ((v[1].y - v[0].y) * cc + (v[3].y - v[2].y) * d2) +
+                 g.z * ((v[1].z - v[0].z) * cc + (v[3].z - v[2].z) * d2) + g.w * ((v[1].w - v[0].w) * cc + (v[3].w - v[2].w) * d2);
+        }
+        // reduce over the 32 lanes that share (p, k): c4n is a multiple of 32
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { dh += __shfl_xor(dh, o, 64); dw += __shfl_xor(dw, o, 64); }
+        if (act && (threadIdx.x & 31) == 0) {
+            atomicAdd(&doffset[(size_t)gp * 18 + 2 * k], dh);
+            atomicAdd(&doffset[(size_t)gp * 18 + 2 * k + 1], dw);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int wd_roi_pool_fpn_bwd_f32(float* const* grad_feats, const int32_t* heights, const int32_t* widths, const float* scales,
+                            int n_levels, int channels, int batch, const float* rois, int n_rois, int pooled, int min_level,
+                            int canonical_level, float canonical_size, const float* grad_out, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (n_levels < 1 || n_levels > kMaxLevels || channels < 1 || pooled < 1) { wt::set_error("wd_roi_pool_fpn_bwd_f32: bad shape"); return WT_ERR_INVALID; }
+    if (n_rois <= 0) return WT_OK;
+    LevelsW lv;
+    for (int i = 0; i < n_levels; ++i) { lv.grad[i] = grad_feats[i]; lv.h[i] = heights[i]; lv.w[i] = widths[i]; lv.scale[i] = scales[i]; }
+    hipLaunchKernelGGL(roi_pool_fpn_bwd_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels,
+                       batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+static int check_deform(int c, int h, int w, int stride) {
+    if (c % 128 || h < 1 || w < 1 || stride < 1) { wt::set_error("deform backward: need C %% 128 == 0 (C=%d)", c); return WT_ERR_INVALID; }
+    return WT_OK;
+}
+
+int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, int w, int c, int stride, int pad, float* col,
+                         void* stream) {
+    WT_TRY(wt::ensure_device());
+    WT_TRY(check_deform(c, h, w, stride));
+    const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
+    const long npix = (long)batch * ho * wo;
+    const long total = npix * 9 * (c / 4);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(deform_im2col_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       x, offset, npix, ho, wo, h, w, c, stride, pad, col);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int stride,
+                         int pad, float* dx, float* doffset, void* stream) {
+    WT_TRY(wt::ensure_device());
+    WT_TRY(check_deform(c, h, w, stride));
+    const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
+    const long npix = (long)batch * ho * wo;
+    const long total = npix * 9 * (c / 4);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(deform_col2im_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
+                       dcol, x, offset, npix, ho, wo, h, w, c, stride, pad, dx, doffset);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+}  // extern "C"

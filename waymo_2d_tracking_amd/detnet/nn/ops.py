@@ -166,3 +166,87 @@ def groupnorm_relu_(x, weight, bias, groups, eps=1e-5, relu=True):
                                                      C.c_int(groups), C.c_float(eps), C.c_int(1 if relu else 0), _stream()),
                'wd_groupnorm_relu_nhwc_f32')
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training (fwd + bwd): autograd wrappers around the forward kernels and the backward kernels of det_backward.hip
+def deform_im2col(x, offset, stride=1, pad=1):
+    """col (P, 9, C) float32, P = N*Ho*Wo (detectron2 deformable_im2col, NHWC order)."""
+    x = _nhwc(x); offset = _nhwc(offset)
+    n, c, h, w = x.shape
+    ho = (h + 2 * pad - 3) // stride + 1
+    wo = (w + 2 * pad - 3) // stride + 1
+    col = torch.empty((n * ho * wo, 9, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().wd_deform_im2col_f32(_p(x), _p(offset), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(stride),
+                                               C.c_int(pad), _p(col), _stream()), 'wd_deform_im2col_f32')
+    return col
+
+
+def deform_col2im(dcol, x, offset, stride=1, pad=1):
+    """dcol (P, 9, C) -> (dx (N,C,H,W) channels_last, doffset (N,18,Ho,Wo) channels_last)."""
+    x = _nhwc(x); offset = _nhwc(offset)
+    dcol = dcol.contiguous()
+    n, c, h, w = x.shape
+    dx = torch.zeros_like(x, memory_format=torch.channels_last)
+    doff = torch.zeros_like(offset, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().wd_deform_col2im_f32(_p(dcol), _p(x), _p(offset), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+                                               C.c_int(stride), C.c_int(pad), _p(dx), _p(doff), _stream()), 'wd_deform_col2im_f32')
+    return dx, doff
+
+
+class DeformConvFn(torch.autograd.Function):
+    """y = DeformConv(x, offset; weight), groups / stride / pad as in the forward kernel (no affine, no ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, weight, groups, stride, pad):
+        packed = deform_pack_weight(weight, groups)
+        y = deform_conv3x3(x, offset, packed, groups, stride, pad)
+        ctx.save_for_backward(x, offset, weight)
+        ctx.cfg = (groups, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, offset, weight = ctx.saved_tensors
+        groups, stride, pad = ctx.cfg
+        cout, cg = weight.shape[0], weight.shape[1]
+        cog = cout // groups
+        dyn = _nhwc(dy).permute(0, 2, 3, 1)
+        p = dyn.shape[0] * dyn.shape[1] * dyn.shape[2]
+        dym = dyn.reshape(p, groups, cog)
+        col = deform_im2col(x, offset, stride, pad).view(p, 9, groups, cg)
+        dw = torch.einsum('pgo,pkgi->goik', dym, col).reshape(cout, cg, 3, 3) if ctx.needs_input_grad[2] else None
+        dx = doff = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wg = weight.view(groups, cog, cg, 9)
+            dcol = torch.einsum('pgo,goik->pkgi', dym, wg).reshape(p, 9, groups * cg)
+            dx, doff = deform_col2im(dcol, x, offset, stride, pad)
+        return dx, doff, dw, None, None, None
+
+
+class RoiPoolFpnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, scales, pooled, min_level, canonical_level, canonical_size, *feats):
+        out = roi_pool_fpn(list(feats), rois, scales, pooled, min_level, canonical_level, canonical_size)
+        ctx.save_for_backward(rois)
+        ctx.cfg = (list(scales), pooled, min_level, canonical_level, canonical_size, [tuple(f.shape) for f in feats])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        rois, = ctx.saved_tensors
+        scales, pooled, min_level, canonical_level, canonical_size, shapes = ctx.cfg
+        gout = _nhwc(gout)
+        grads = [torch.zeros(s, dtype=torch.float32, device=gout.device).contiguous(memory_format=torch.channels_last) for s in shapes]
+        nl = len(grads)
+        ptrs = (C.c_void_p * nl)(*[g.data_ptr() for g in grads])
+        hs = (C.c_int32 * nl)(*[s[2] for s in shapes])
+        ws = (C.c_int32 * nl)(*[s[3] for s in shapes])
+        sc = (C.c_float * nl)(*[float(s) for s in scales])
+        r = rois.shape[0]
+        if r:
+            _lib.check(_lib.lib().wd_roi_pool_fpn_bwd_f32(ptrs, hs, ws, sc, C.c_int(nl), C.c_int(shapes[0][1]), C.c_int(shapes[0][0]),
+                                                          _p(rois.contiguous().float()), C.c_int(r), C.c_int(pooled), C.c_int(min_level),
+                                                          C.c_int(canonical_level), C.c_float(canonical_size), _p(gout), _stream()),
+                       'wd_roi_pool_fpn_bwd_f32')
+        return (None, None, None, None, None, None) + tuple(grads)
