@@ -58,6 +58,13 @@ class Conv1x1(nn.Module):
         n, c, h, w = x.shape
         a = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
         r = None if residual is None else residual.permute(0, 2, 3, 1).reshape(n * h * w, -1)
+        if torch.is_grad_enabled():                      # training fwd+bwd: autograd-visible library ops
+            y = F.linear(a, self.weight, self.bias)
+            if r is not None:
+                y = y + r
+            if relu:
+                y = F.relu(y)
+            return y.view(n, h, w, -1).permute(0, 3, 1, 2)
         if not self.USE_LIBRARY_GEMM:
             y = ops.gemm_nt(a, self.weight, self.bias, r, relu)
         elif r is None:
@@ -115,14 +122,20 @@ class Bottleneck(nn.Module):
         self.conv3 = Conv1x1(width, cout, gen, bn_scale=0.25)   # keeps random-init activations bounded over 50 blocks
 
     def packed_weight(self):
-        if self._packed is None or self._packed.device != self.conv2_weight.device:
-            self._packed = ops.deform_pack_weight(self.conv2_weight, GROUPS)
+        v = self.conv2_weight._version
+        if self._packed is None or self._packed.device != self.conv2_weight.device or getattr(self, '_packed_v', -1) != v:
+            self._packed = ops.deform_pack_weight(self.conv2_weight, GROUPS)     # re-packed after an optimizer step
+            self._packed_v = v
         return self._packed
 
     def forward(self, x):
         sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)
         out = self.conv1(x, relu=True)
-        if self.deform:
+        if self.deform and torch.is_grad_enabled():      # training: autograd Function around the HIP fwd / bwd kernels
+            offset = self.conv2_offset(out)
+            out = ops.DeformConvFn.apply(out, offset, self.conv2_weight, GROUPS, self.stride, 1)
+            out = F.relu(out * self.conv2_scale.view(1, -1, 1, 1) + self.conv2_bias.view(1, -1, 1, 1))
+        elif self.deform:
             offset = self.conv2_offset(out)
             out = ops.deform_conv3x3(out, offset, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
                                      self.conv2_bias, relu=True)
@@ -150,9 +163,11 @@ class ResNeXt152FPN(nn.Module):
         self.output = nn.ModuleList([ConvBN(256, 256, 3, 1, 1, 1, gen, bias=True) for _ in STAGE_CH])
 
     def forward(self, x):
-        x = self.stem(x, relu=True)
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
-        c2 = self.res2(x); c3 = self.res3(c2); c4 = self.res4(c3); c5 = self.res5(c4)
+        with torch.no_grad():                                # FREEZE_AT = 2: stem and res2 never train (job.log:219)
+            x = self.stem(x, relu=True)
+            x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+            c2 = self.res2(x)
+        c3 = self.res3(c2); c4 = self.res4(c3); c5 = self.res5(c4)
         feats = [c2, c3, c4, c5]
         prev = self.lateral[3](c5)
         outs = [self.output[3](prev)]
@@ -266,14 +281,21 @@ class BoxHead(nn.Module):
         self.box_bias = nn.Parameter(torch.zeros(4), requires_grad=False)
 
     def forward(self, x):
+        train = torch.is_grad_enabled()
         for conv, norm in zip(self.convs, self.norms):
             x = conv(x)
+            if train:
+                x = F.relu(norm(x))
+                continue
             if not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)
             x = ops.groupnorm_relu_(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True)
         r = x.shape[0]
         flat = x.permute(0, 2, 3, 1).reshape(r, -1)           # NHWC flatten, a view
-        h = ops.gemm_nt(flat, self.fc1_weight, self.fc1_bias, None, True)
+        if train:
+            h = F.relu(F.linear(flat, self.fc1_weight, self.fc1_bias))
+        else:
+            h = ops.gemm_nt(flat, self.fc1_weight, self.fc1_bias, None, True)
         logits = F.linear(h, self.cls_weight, self.cls_bias)
         deltas = F.linear(h, self.box_weight, self.box_bias)
         return logits, deltas
@@ -303,8 +325,11 @@ class CascadeRCNN(nn.Module):
             x = F.pad(x, (0, pw, 0, ph))
         return x.contiguous(memory_format=torch.channels_last)
 
-    @torch.no_grad()
     def forward(self, image_bgr, proposals=None, intermediates=None):
+        with torch.no_grad():
+            return self._forward_inference(image_bgr, proposals, intermediates)
+
+    def _forward_inference(self, image_bgr, proposals=None, intermediates=None):
         """One image (1,3,H,W) -> (boxes (K,4) xyxy pixels, scores (K), classes (K) int64), K <= topk.
         `proposals` overrides the RPN output and `intermediates` (a dict) receives feature maps / stage outputs:
         both are test hooks."""

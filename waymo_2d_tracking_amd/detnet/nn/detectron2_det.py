@@ -34,6 +34,23 @@ class Detectron2Det(Module):
         x = self(x.to(next(self.parameters())))
         return [self.model(x[i:i + 1]) for i in range(x.shape[0])]
 
+    def criterion(self, args=None):
+        """detectron2_det/__init__.py:141-142"""
+        return self.loss
+
+    def loss(self, images, target):
+        """detectron2_det/__init__.py:144-186: images (B,3,H,W) RGB 0..255, target = {'labels': [LongTensor (n_i) 1-based],
+        'boxes': [Tensor (n_i,4) xyxy pixels]} -> dict of loss tensors (summed over the batch / B)."""
+        from . import training
+        x = self(images.to(next(self.parameters())))
+        total = {}
+        for i in range(x.shape[0]):
+            boxes = target['boxes'][i].to(x.device).float()
+            classes = (target['labels'][i].to(x.device).long() - 1)
+            for k, v in training.losses(self.model, x[i:i + 1], boxes, classes).items():
+                total[k] = total.get(k, 0) + v / x.shape[0]
+        return total
+
     def predict(self, x):
         single = False
         if not torch.is_tensor(x):                              # PIL image (:103-107)
