@@ -9,6 +9,7 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
   detect   the detector alone (config 2).
   track    SORT alone on pre-computed detections (config 1 scaled to --segments segments per GPU).
   ensemble soft-NMS ensemble alone (config 4: K=13 inputs).
+  train    one training step fwd+bwd+SGD (config 5), DDP over RCCL for N > 1.
 Multi-GPU: one process per GPU (torchrun), camera sequences / frames sharded with no data-path collective in
 the timed region (weak scaling); the only exchange is the ID-offset all_gather + result gather done by the CLIs.
 Rank 0 prints ONE JSON line with `roofline` (dominant hand-written kernel, HIP-event timed) and `cpu_baseline`
@@ -35,7 +36,7 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--stage', default=os.environ.get('WT_BENCH_STAGE', 'e2e'),
-                    choices=['e2e', 'detect', 'track', 'ensemble'])
+                    choices=['e2e', 'detect', 'track', 'ensemble', 'train'])
     ap.add_argument('--segments', type=int, default=8, help='track stage: segments (x5 cameras x198 frames) per GPU')
     ap.add_argument('--images', type=int, default=990, help='ensemble stage: images per GPU')
     ap.add_argument('--k-inputs', type=int, default=13)
@@ -258,6 +259,10 @@ def main():
     elif args.stage == 'ensemble':
         res, steps, warmup = stage_ensemble(args, world, rank)
         metric = 'soft-NMS ensemble images/sec'
+    elif args.stage == 'train':
+        from waymo_2d_tracking_amd import bench_e2e
+        res, steps, warmup = bench_e2e.run_train(args, world, rank, timed_steps)
+        metric = 'training images/sec (fwd+bwd+step), Cascade R-CNN X152 dconv, 886x1280 crops'
     else:
         from waymo_2d_tracking_amd import bench_e2e
         res, steps, warmup = bench_e2e.run(args, world, rank, timed_steps)

@@ -132,3 +132,53 @@ def run(args, world, rank, timed_steps):
                extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births))
     res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters
     return res, steps, warmup
+
+
+def run_train(args, world, rank, timed_steps):
+    """Config 5: Cascade R-CNN X152 dconv training fwd+bwd+SGD step, 886x1280 crop (train.py:37-47), batch 1 per
+    GPU, DDP over RCCL when world > 1 (bucketed gradient all-reduce overlapped with backward)."""
+    import torch.nn as nn
+    from .detnet.nn import training
+    from .detnet.nn.detectron2_det import Detectron2Det
+    torch.backends.cudnn.benchmark = True
+    dev = torch.device('cuda')
+    det = Detectron2Det(seed=0).to(dev).train()
+    params = training.set_trainable(det.model)
+
+    class Wrapper(nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+        def forward(self, image_bgr, boxes, classes):
+            return sum(training.losses(self.model, image_bgr, boxes, classes).values())
+
+    net = Wrapper(det.model)
+    if world > 1:
+        net = nn.parallel.DistributedDataParallel(net, device_ids=[torch.cuda.current_device()])
+    opt = torch.optim.SGD(params, lr=0.002, momentum=0.9, weight_decay=1e-4)       # detnet/configs/detectron2.cfg
+    g = torch.Generator().manual_seed(rank)
+    img = torch.randint(0, 256, (1, 3, 886, 1280), generator=g).float().to(dev)
+    n = 30
+    wh = torch.rand((n, 2), generator=g) * 280 + 20
+    xy = torch.rand((n, 2), generator=g) * torch.tensor([1280 - 300.0, 886 - 300.0])
+    boxes = torch.cat((xy, xy + wh), 1).to(dev)
+    classes = torch.randint(0, 4, (n,), generator=g).to(dev)
+    last = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = net(img, boxes, classes)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 35.0)
+        opt.step()
+        last['loss'] = loss.detach()
+
+    steps = args.steps or 3
+    warmup = args.warmup if args.warmup is not None else 1
+    dt, ev_ms = timed_steps(world, step, steps, warmup)
+    res = dict(value=world * steps / dt, unit='images/s', ms_per_step=1e3 * dt / steps, dtype='f32',
+               workload='Cascade R-CNN X152-32x8d-FPN dconv training step (fwd+bwd+SGD), 886x1280 crop, batch 1/GPU, '
+                        '30 synthetic gt boxes, FREEZE_AT 2, FrozenBN, %s' % ('DDP x%d over RCCL' % world if world > 1 else 'single GPU'),
+               extra=dict(loss=float(last['loss']), trainable_params=sum(p.numel() for p in params)))
+    return res, steps, warmup
