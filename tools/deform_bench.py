@@ -17,7 +17,7 @@ for name, C, H, W, stride, deform in [('res2', 256, 320, 480, 1, False), ('res3'
                                       ('res4', 1024, 80, 120, 1, True), ('res5', 2048, 40, 60, 1, True)]:
     x = torch.randn(1, C, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
     Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
-    off = (torch.randn(1, 18, Ho, Wo, device='cuda') * 1.5).contiguous(memory_format=torch.channels_last) if deform else None
+    off = (torch.randn(1, 18, Ho, Wo, device="cuda") * float(os.environ.get("OFF_STD", "1.5"))).contiguous(memory_format=torch.channels_last) if deform else None
     w = torch.randn(C, C // 32, 3, 3, device='cuda')
     pw = ops.deform_pack_weight(w, 32)
     sc = torch.ones(C, device='cuda'); bi = torch.zeros(C, device='cuda')

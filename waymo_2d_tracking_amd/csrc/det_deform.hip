@@ -13,6 +13,7 @@
 // Per layer: 2*C_out*(C_in/groups)*9*H_out*W_out flops (5.66 GFLOP for every res3/res4/res5 layer at 1920x1280).
 #include "common.h"
 #include "../../include/waymodet.h"
+#include <cstdlib>
 
 namespace {
 
@@ -208,6 +209,168 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
     }
 }
 
+
+// ---- stride-1 fast path: the input patch of the tile is staged ONCE in LDS ----------------------------------------
+// The v2 kernel above gathers every (pixel, tap, corner) from L1/L2: 64 x 9 x 4 = 2304 corner reads of 512 B per
+// workgroup, which made it L1-bandwidth bound at ~45 TFLOP/s.  Here the 14 x 14 input pixels around an 8 x 8 output
+// tile (10 x 10 undeformed footprint + a 2-pixel halo for the learned offsets) are loaded once per 64-channel chunk
+// (196 coalesced 256-byte rows, zero-filled outside the image) and all bilinear corners are read from LDS with
+// conflict-free ds_read_b128 (16 lanes = the 64 channels of one patch pixel).  Samples whose corners leave the patch
+// (|offset| > ~2 px) fall back to global loads for that (pixel, tap).  Slab, MFMA and epilogue as in v2.
+constexpr int PCH = 64;              // channels per workgroup
+constexpr int PR = 2;                // halo in pixels
+constexpr int PS = 10 + 2 * PR;      // patch side
+constexpr int LDP = PCH + 2;         // slab row stride (== 2 mod 32: conflict-free A-fragment reads, 8-byte aligned rows)
+
+template <int CG>
+__global__ __launch_bounds__(256, 2) void deform_conv3x3_patch_kernel(
+    const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
+    const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ bias, int relu,
+    int batch, int H, int W, int C, int Cout, int Ho, int Wo, float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float patch[PS * PS * PCH];
+    __shared__ __attribute__((aligned(16))) float col[TP * LDP];
+    __shared__ float offs[TP * 18];
+    __shared__ float msk[TP * 9];
+    __shared__ int pix[TP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
+    const int ntiles = batch * tiles_y * tiles_x;
+    const int nchunks = C / PCH;
+    int tile, chunk;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        if ((nchunks & 7) == 0) {                    // whole channel chunks per XCD (see the v2 kernel)
+            const int cpx = nchunks >> 3;
+            chunk = xcd * cpx + slot % cpx;
+            tile = slot / cpx;
+        } else {
+            chunk = b / ntiles;
+            tile = b - chunk * ntiles;
+        }
+    }
+    if (tile >= ntiles || chunk >= nchunks) return;
+    const int tn = tile / (tiles_y * tiles_x);
+    const int trem = tile - tn * tiles_y * tiles_x;
+    const int tyy = trem / tiles_x, txx = trem - tyy * tiles_x;
+    const int c0 = chunk * PCH;
+    const int py0 = tyy * 8 - 1 - PR, px0 = txx * 8 - 1 - PR;       // image coordinates of patch pixel (0, 0)
+    if (tid < TP) {
+        const int ho = tyy * 8 + (tid >> 3), wo = txx * 8 + (tid & 7);
+        pix[tid] = (ho < Ho && wo < Wo) ? (tn * Ho + ho) * Wo + wo : -1;
+    }
+    // ---- stage the patch (zero outside the image) ----
+    for (int e = tid; e < PS * PS * (PCH / 4); e += 256) {
+        const int pp = e >> 4, q = e & 15;
+        const int r = pp / PS, cc = pp - r * PS;
+        const int iy = py0 + r, ix = px0 + cc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+            v = *reinterpret_cast<const float4*>(x + ((size_t)(tn * H + iy) * W + ix) * C + c0 + q * 4);
+        *reinterpret_cast<float4*>(&patch[pp * PCH + q * 4]) = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < TP * 18; e += 256) {
+        const int p = e / 18;
+        const int gp = pix[p];
+        offs[e] = gp >= 0 ? offset[(size_t)gp * 18 + (e - 18 * p)] : 0.f;
+    }
+    for (int e = tid; e < TP * 9; e += 256) {
+        const int p = e / 9;
+        const int gp = pix[p];
+        msk[e] = (gp >= 0) ? (mask ? mask[(size_t)gp * 9 + (e - 9 * p)] : 1.f) : 0.f;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int gq = tid & 15;            // float4 column of the 64-channel slab
+    const int gp0 = tid >> 4;           // first pixel (pixels gp0, gp0 + 16, ...)
+    const int co_l = wave * 16;         // this wave's 16 output channels inside the chunk
+    const int g_l = co_l / CG;
+    const int g = (c0 + co_l) / CG;
+    const int co_g = (co_l % CG) + (lane & 15);
+    for (int k = 0; k < 9; ++k) {
+        const int kh = k / 3, kw = k - 3 * kh;
+        // weights of this tap first: their L2 latency hides behind the gather phase instead of stalling the MFMAs
+        float breg[CG / 4];
+        {
+            const float* wb = wp + ((size_t)(g * 9 + k) * CG) * CG + co_g;
+#pragma unroll
+            for (int kk = 0; kk < CG / 4; ++kk) breg[kk] = wb[(size_t)(kk * 4 + (lane >> 4)) * CG];
+        }
+        // ---- gather from the LDS patch ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = gp0 + 16 * i;
+            const float ry = (float)((p >> 3) + kh + PR) + offs[p * 18 + 2 * k];       // patch coordinates
+            const float rx = (float)((p & 7) + kw + PR) + offs[p * 18 + 2 * k + 1];
+            const float h_im = ry + (float)py0, w_im = rx + (float)px0;
+            const float m = msk[p * 9 + k];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m != 0.f && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const float fy = floorf(ry), fx = floorf(rx);
+                const int hl = (int)fy, wl = (int)fx;
+                const float lh = ry - fy, lw = rx - fx, uh = 1.f - lh, uw = 1.f - lw;
+                if (hl >= 0 && hl < PS - 1 && wl >= 0 && wl < PS - 1) {
+                    const float* pb = &patch[(hl * PS + wl) * PCH + gq * 4];
+                    const float4 a = *reinterpret_cast<const float4*>(pb);
+                    const float4 b = *reinterpret_cast<const float4*>(pb + PCH);
+                    const float4 c = *reinterpret_cast<const float4*>(pb + PS * PCH);
+                    const float4 d = *reinterpret_cast<const float4*>(pb + PS * PCH + PCH);
+                    const float w1 = uh * uw, w2 = uh * lw, w3 = lh * uw, w4 = lh * lw;
+                    v.x = w1 * a.x + w2 * b.x + w3 * c.x + w4 * d.x;
+                    v.y = w1 * a.y + w2 * b.y + w3 * c.y + w4 * d.y;
+                    v.z = w1 * a.z + w2 * b.z + w3 * c.z + w4 * d.z;
+                    v.w = w1 * a.w + w2 * b.w + w3 * c.w + w4 * d.w;
+                } else {                                  // large offset: corners from global memory
+                    const int ih = hl + py0, iw = wl + px0;
+                    const float wq[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int yy = ih + (qd >> 1), xx = iw + (qd & 1);
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                            const float4 t = *reinterpret_cast<const float4*>(x + ((size_t)(tn * H + yy) * W + xx) * C + c0 + gq * 4);
+                            v.x += wq[qd] * t.x; v.y += wq[qd] * t.y; v.z += wq[qd] * t.z; v.w += wq[qd] * t.w;
+                        }
+                    }
+                }
+                v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            }
+            float2* dd = reinterpret_cast<float2*>(&col[p * LDP + gq * 4]);
+            dd[0] = make_float2(v.x, v.y);
+            dd[1] = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+        // ---- MFMA: out[64 px][16 co of this wave] += slab[64 px][ci of the group] * W[ci][co] ----
+#pragma unroll
+        for (int kk = 0; kk < CG / 4; ++kk) {
+            const int ci = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float a = col[(mt * 16 + (lane & 15)) * LDP + g_l * CG + ci];
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[kk], acc[mt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int co = c0 + co_l + (lane & 15);
+    const float sc = scale ? scale[co] : 1.f;
+    const float bi = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long gp = pix[mt * 16 + (lane >> 4) * 4 + r];
+            if (gp >= 0) {
+                float v = acc[mt][r] * sc + bi;
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)gp * Cout + co] = v;
+            }
+        }
+}
+
 // (C_out, C_in/groups, 3, 3) OIHW -> [group][tap][ci][co]
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout, float* __restrict__ packed) {
     const long total = (long)cout * cg * 9;
@@ -259,6 +422,24 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
     const long nwg = ntiles * (c_in / CCH);
     dim3 grid((unsigned)((nwg + 7) / 8 * 8));
     hipStream_t stream = (hipStream_t)stream_;
+    // measured on MI355X (tools/deform_bench.py): the LDS-patch kernel wins for 64 channels per group (res5: 96 vs
+    // 110 us) and loses to the L1-gather kernel for 16 / 32 (res3 / res4), where its smaller 64-channel chunks
+    // expose the per-tap barrier latency; WD_DEFORM_PATCH=all|none overrides for experiments
+    const char* mode = getenv("WD_DEFORM_PATCH");
+    const bool want_patch = mode ? (strcmp(mode, "all") == 0) : (cg == 64);
+    if (offset && stride == 1 && pad == 1 && (cg == 16 || cg == 32 || cg == 64) && want_patch) {
+        const long nwg_p = ntiles * (c_in / PCH);
+        dim3 gridp((unsigned)((nwg_p + 7) / 8 * 8));
+#define WD_LAUNCH_P(CG)                                                                                              \
+    hipLaunchKernelGGL(deform_conv3x3_patch_kernel<CG>, gridp, dim3(256), 0, stream, x, offset, mask, packed_weight, \
+                       scale, bias, relu, batch, h, w, c_in, c_out, ho, wo, y)
+        if (cg == 16) WD_LAUNCH_P(16);
+        else if (cg == 32) WD_LAUNCH_P(32);
+        else WD_LAUNCH_P(64);
+#undef WD_LAUNCH_P
+        WT_HIP(hipGetLastError());
+        return WT_OK;
+    }
 #define WD_LAUNCH(CG)                                                                                                     \
     do {                                                                                                                  \
         if (offset)                                                                                                       \
