@@ -121,6 +121,36 @@ int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const
                          int64_t* out_object_id, int64_t* n_out_dev, int64_t* n_births_dev,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Native COCO-JSON I/O around the tracking stage (host code).
+ * wt_detfile_read = json.load + read_data_file (tracking/utils.py:63-96: "annotations" wrapper, w/h < 1 and
+ * per-class score filters, frame keys kept for fully filtered frames, missing score = 1.0) + the stream / frame
+ * ordering of tracking/track.py:43-47 and utils.py:31, straight into the SoA / CSR layout of wt_track_streams_*.
+ * The accessors return pointers owned by the handle (valid until wt_detfile_free). */
+typedef struct wt_detfile wt_detfile;
+int wt_detfile_read(const char* path, const double* score_threshold, int n_classes, wt_detfile** out);
+void wt_detfile_free(wt_detfile* f);
+int64_t wt_detfile_num_dets(const wt_detfile* f);
+int64_t wt_detfile_num_frames(const wt_detfile* f);
+int32_t wt_detfile_num_streams(const wt_detfile* f);
+const double* wt_detfile_x(const wt_detfile* f);
+const double* wt_detfile_y(const wt_detfile* f);
+const double* wt_detfile_w(const wt_detfile* f);
+const double* wt_detfile_h(const wt_detfile* f);
+const double* wt_detfile_score(const wt_detfile* f);
+const int32_t* wt_detfile_category(const wt_detfile* f);
+const int64_t* wt_detfile_frame_det_offsets(const wt_detfile* f);
+const int64_t* wt_detfile_stream_frame_offsets(const wt_detfile* f);
+const int64_t* wt_detfile_frame_ids(const wt_detfile* f);
+const char* wt_detfile_segment(const wt_detfile* f, int32_t stream);
+const char* wt_detfile_camera(const wt_detfile* f, int32_t stream);
+/* json.dump of the tracking rows (tracking/utils.py:52-58, tracking/track.py:50), byte-compatible with Python:
+ * [{"image_id": "<segment>/<frame>/<camera>", "bbox": [x1, y1, w, h], "score": s, "category_id": c,
+ *   "object_id": "<id>"}, ...]; floats in Python repr form.  Rows as produced by wt_track_streams_*. */
+int wt_tracks_write_json(const char* path, const wt_detfile* f, int64_t n, const int64_t* frame, const int32_t* category,
+                         const double* bbox4, const double* score, const int64_t* object_id);
+/* Python repr() of a double (shortest round-trip digits); returns the length or -1 if cap is too small. */
+int wt_format_double(double v, char* out, int cap);
+
 /* =================================================================================================
  * soft-NMS / NMS / weighted-fusion ensemble
  * (detnet/utils/box_utils.py, detnet/nn/tta.py, detnet/ensemble.py)

@@ -52,6 +52,13 @@ def test_cli_track_golden(golden_dir, tmp_path, capsys):
     got = json.load(open(out))
     assert _rows(got) == _rows(exp['tracks'])
     assert set(got[0].keys()) == {'image_id', 'bbox', 'score', 'category_id', 'object_id'}
+    # the native-I/O default and the Python-json path write the same bytes
+    T.reset_global_ids(0)
+    out2 = tmp_path / 'tracks_py.json'
+    assert track.main(['--input', os.path.join(golden_dir, 'sort_g4_input.json'), '--output', str(out2), '--max-age=2',
+                       '--min-hits=0', '--score-threshold=0.3,0.3,1.0,0.2', '--iou-threshold=0.01,0.01,1.0,0.0',
+                       '--python-io']) == 0
+    assert open(out, 'rb').read() == open(out2, 'rb').read()
 
 
 def test_track_sort_api_per_stream_matches_batch(golden_dir):

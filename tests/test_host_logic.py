@@ -66,3 +66,66 @@ def test_inference_cli_flags():
     from waymo_2d_tracking_amd.detnet.inference import build_parser
     a = build_parser().parse_args(['-i', 'imgs', '--export', 's.json', '--tta', 'x1.5,hflip', '--batch-size=1', '-j', '8'])
     assert a.tta == 'x1.5,hflip' and a.export == 's.json' and a.threshold == 0.01
+
+
+def _lib_or_skip():
+    from waymo_2d_tracking_amd import build
+    build.build(verbose=False)
+    from waymo_2d_tracking_amd.tracking import utils as T
+    return T
+
+
+@pytest.mark.parametrize('fixture,thr', [('sort_g4_input.json', [0.3, 0.3, 1.0, 0.2]), ('sort_g5_input.json', [0.95, 0.6, 1.0, 0.9]),
+                                         ('sort_g4_input.json', [0.0, 0.0, 0.0, 0.0])])
+def test_native_json_reader_matches_python_path(golden_dir, fixture, thr):
+    """wt_detfile_read == read_data_file + pack_streams (filters, empty frames, stream / frame order, dtypes)."""
+    T = _lib_or_skip()
+    path = os.path.join(golden_dir, fixture)
+    ref = T.pack_streams(T.read_data_file(path, thr))
+    nat = T.NativeDetFile(path, thr)
+    got = nat.packed()
+    assert got['stream_keys'] == ref['stream_keys']
+    for k in ('x', 'y', 'w', 'h', 'score', 'category', 'frame_det_offsets', 'stream_frame_offsets', 'frame_ids', 'clip_w', 'clip_h'):
+        assert np.array_equal(got[k], ref[k]), k
+    nat.close()
+
+
+def test_native_json_writer_is_byte_identical_to_json_dump(golden_dir, tmp_path):
+    """wt_tracks_write_json == json.dump(format_tracks(...)) byte for byte (Python float repr, separators, key order)."""
+    T = _lib_or_skip()
+    exp = json.load(open(os.path.join(golden_dir, 'sort_g4_expected_a.json')))
+    p = exp['params']
+    path = os.path.join(golden_dir, 'sort_g4_input.json')
+    nat = T.NativeDetFile(path, p['score_threshold'])
+    packed = nat.packed()
+    rng = np.random.default_rng(0)
+    n = 500
+    frames = np.sort(rng.integers(0, len(packed['frame_ids']), n))
+    out = dict(frame=frames, category=rng.integers(1, 5, n).astype(np.int32),
+               bbox=np.concatenate([rng.uniform(0, 1900, (n, 2)), rng.uniform(1, 300, (n, 2))], axis=1),
+               score=rng.uniform(0.2, 1.0, n), object_id=rng.integers(1, 10 ** 6, n))
+    out['bbox'][::7] = np.round(out['bbox'][::7])                 # integral floats -> "12.0"
+    out['bbox'][3] = [0.0, 1e-5, 123456789012345678.0, 1e16]      # exponent forms, zero
+    out['score'][5] = 0.1 + 0.2                                    # 0.30000000000000004
+    a, b = tmp_path / 'native.json', tmp_path / 'python.json'
+    nat.write_tracks(a, out)
+    with open(b, 'wt') as fp:
+        json.dump(T.format_tracks(packed, out), fp)
+    assert open(a, 'rb').read() == open(b, 'rb').read()
+    nat.close()
+
+
+def test_python_float_repr_port():
+    import ctypes as C
+    _lib_or_skip()
+    from waymo_2d_tracking_amd import _lib
+    lib = _lib.lib()
+    buf = C.create_string_buffer(64)
+    rng = np.random.default_rng(1)
+    vals = [0.0, -0.0, 1.0, -1.5, 1e-4, 1e-5, 123456.789, 1e15, 1e16, 1e22, 5e-324, 1.7976931348623157e308, 0.1, 1 / 3, 2.5e-7,
+            float('nan'), float('inf'), -float('inf')]
+    vals += list(rng.uniform(-1e6, 1e6, 200)) + list(10.0 ** rng.uniform(-20, 20, 200))
+    for v in vals:
+        n = lib.wt_format_double(C.c_double(v), buf, 64)
+        assert n > 0
+        assert buf.value.decode() == json.dumps(float(v)), (v, buf.value, json.dumps(float(v)))

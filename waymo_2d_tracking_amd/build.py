@@ -22,6 +22,7 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-mat
 # unit -> extra flags
 UNITS = {
     'api.hip': [],
+    'json_io.hip': [],
     'ensemble.hip': ['-ffp-contract=off'],
     'sort_engine.hip': ['-ffp-contract=off'],
     'sort_single.hip': ['-ffp-contract=off'],

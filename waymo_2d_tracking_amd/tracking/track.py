@@ -34,12 +34,32 @@ def build_parser():
     parser.add_argument("--iou-threshold", type=_floats, default=[0.01, 0.01, 1.0, 0.0],
                         help='IOU threshold for tracking')
     parser.add_argument("--segment-id", type=str, help='track only a single segment')
+    parser.add_argument("--python-io", action='store_true',
+                        help='parse / write JSON with the Python json module (default: native reader / writer of libwaymotrack)')
     return parser
+
+
+def main_native(args):
+    """file -> SoA in HBM -> file without per-row Python objects (wt_detfile_read / wt_tracks_write_json)."""
+    from . import utils as T
+    nat = T.NativeDetFile(args.input, args.score_threshold)
+    packed = nat.packed()
+    start_time = time.time()
+    for segment_id in dict.fromkeys(s for s, _ in packed['stream_keys']):
+        print(segment_id)
+    out, births = T.track_packed(packed, args.iou_threshold, args.max_age, args.min_hits, None, T._GLOBAL_IDS['next'])
+    T._GLOBAL_IDS['next'] += births
+    print("duration: %.2fs" % (time.time() - start_time))
+    nat.write_tracks(args.output, out)
+    nat.close()
+    return 0
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print(args)
+    if not args.python_io and not args.segment_id and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        return main_native(args)
     predictions = read_data_file(args.input, args.score_threshold)
     if args.segment_id:
         predictions = {k: v for k, v in predictions.items() if k in [args.segment_id]}

@@ -178,3 +178,63 @@ def track_all(predictions, iou_thresholds, max_age, min_hits, segment_ids=None):
     out, births = track_packed(packed, iou_thresholds, max_age, min_hits, None, _GLOBAL_IDS['next'])
     _GLOBAL_IDS['next'] += births
     return format_tracks(packed, out)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# native JSON I/O (include/waymotrack.h, wt_detfile_* / wt_tracks_write_json): the same result as
+# read_data_file + pack_streams / json.dump(format_tracks(...)) without building Python objects per row
+class NativeDetFile(object):
+    def __init__(self, path, score_threshold):
+        lib = _lib.lib()
+        st = _lib.as_f64(score_threshold)
+        self._keep = st
+        h = C.c_void_p()
+        _lib.check(lib.wt_detfile_read(str(path).encode(), _lib.ptr(st), C.c_int(len(st)), C.byref(h)), 'wt_detfile_read')
+        self._h = h
+        self.lib = lib
+
+    def packed(self):
+        """The dict pack_streams() would return (numpy views copied out of the handle)."""
+        lib, h = self.lib, self._h
+        for name, rt in (('wt_detfile_num_dets', C.c_int64), ('wt_detfile_num_frames', C.c_int64),
+                         ('wt_detfile_num_streams', C.c_int32), ('wt_detfile_segment', C.c_char_p),
+                         ('wt_detfile_camera', C.c_char_p)):
+            getattr(lib, name).restype = rt
+        n, nf, ns = lib.wt_detfile_num_dets(h), lib.wt_detfile_num_frames(h), lib.wt_detfile_num_streams(h)
+
+        def arr(fn, count, ctype, dtype):
+            f = getattr(lib, fn)
+            f.restype = C.POINTER(ctype)
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(f(h), shape=(count,)).astype(dtype, copy=True)
+        keys = [(lib.wt_detfile_segment(h, C.c_int32(s)).decode(), lib.wt_detfile_camera(h, C.c_int32(s)).decode())
+                for s in range(ns)]
+        clip = [IMAGE_SIZES.get(c) or [0.0, 0.0] for _, c in keys]
+        return dict(
+            x=arr('wt_detfile_x', n, C.c_double, np.float64), y=arr('wt_detfile_y', n, C.c_double, np.float64),
+            w=arr('wt_detfile_w', n, C.c_double, np.float64), h=arr('wt_detfile_h', n, C.c_double, np.float64),
+            score=arr('wt_detfile_score', n, C.c_double, np.float64),
+            category=arr('wt_detfile_category', n, C.c_int32, np.int32),
+            frame_det_offsets=arr('wt_detfile_frame_det_offsets', nf + 1, C.c_int64, np.int64),
+            stream_frame_offsets=arr('wt_detfile_stream_frame_offsets', ns + 1, C.c_int64, np.int64),
+            frame_ids=arr('wt_detfile_frame_ids', nf, C.c_int64, np.int64),
+            clip_w=np.asarray([c[0] for c in clip], dtype=np.float64), clip_h=np.asarray([c[1] for c in clip], dtype=np.float64),
+            stream_keys=keys)
+
+    def write_tracks(self, path, out):
+        n = len(out['frame'])
+        fr = np.ascontiguousarray(out['frame'], dtype=np.int64)
+        cat = np.ascontiguousarray(out['category'], dtype=np.int32)
+        bb = np.ascontiguousarray(out['bbox'], dtype=np.float64)
+        sc = np.ascontiguousarray(out['score'], dtype=np.float64)
+        oid = np.ascontiguousarray(out['object_id'], dtype=np.int64)
+        _lib.check(self.lib.wt_tracks_write_json(str(path).encode(), self._h, C.c_int64(n), _lib.ptr(fr), _lib.ptr(cat),
+                                                 _lib.ptr(bb), _lib.ptr(sc), _lib.ptr(oid)), 'wt_tracks_write_json')
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.wt_detfile_free(self._h)
+            self._h = None
+
+    __del__ = close
