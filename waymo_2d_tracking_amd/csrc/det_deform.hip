@@ -119,38 +119,52 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
     const int gq = tid & 31;           // float4 column of the slab this thread gathers
     const int gp0 = tid >> 5;          // first pixel row (rows gp0, gp0 + 8, ...)
     const int co_w = wave * 32;        // this wave's 32 output channels inside the chunk
-    for (int k = 0; k < 9; ++k) {
-        // ---- 2. gather + blend the tap's im2col slab: 16 independent 16-byte loads in flight per lane ----
+    // Software pipeline: the first half of tap k+1's gather (16 x 16-byte loads per lane) is issued right after the
+    // slab barrier and stays in flight under the MFMAs of tap k (PMC on the unpipelined loop: 53 % of wave cycles in
+    // s_waitcnt / barriers, 14 % issuing); only the second half's latency is exposed.
+    constexpr int NQ = DEFORM ? 4 : 1;
+    float4 tA[4][NQ];
+    float wA[4][NQ];
+    auto issue = [&](int k, int half, float4 (&t)[4][NQ], float (&wq)[4][NQ]) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            constexpr int NQ = DEFORM ? 4 : 1;
-            float4 t[4][NQ];
-            float wq[4][NQ];
+        for (int i = 0; i < 4; ++i) {
+            const int p = gp0 + 8 * (half * 4 + i);
+            const Sample s = tab[p * 9 + k];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = gp0 + 8 * (half * 4 + i);
-                const Sample s = tab[p * 9 + k];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    t[i][q] = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
-                    wq[i][q] = s.wgt[q];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = gp0 + 8 * (half * 4 + i);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    v.x += wq[i][q] * t[i][q].x; v.y += wq[i][q] * t[i][q].y;
-                    v.z += wq[i][q] * t[i][q].z; v.w += wq[i][q] * t[i][q].w;
-                }
-                float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
-                d[0] = make_float2(v.x, v.y);
-                d[1] = make_float2(v.z, v.w);
+            for (int q = 0; q < NQ; ++q) {
+                t[i][q] = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
+                wq[i][q] = s.wgt[q];
             }
         }
+    };
+    auto blend = [&](int half, const float4 (&t)[4][NQ], const float (&wq)[4][NQ]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = gp0 + 8 * (half * 4 + i);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                v.x += wq[i][q] * t[i][q].x; v.y += wq[i][q] * t[i][q].y;
+                v.z += wq[i][q] * t[i][q].z; v.w += wq[i][q] * t[i][q].w;
+            }
+            float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+        }
+    };
+    issue(0, 0, tA, wA);
+    for (int k = 0; k < 9; ++k) {
+        // ---- 2. gather + blend the tap's im2col slab ----
+        blend(0, tA, wA);
+        {
+            float4 tB[4][NQ];
+            float wB[4][NQ];
+            issue(k, 1, tB, wB);
+            blend(1, tB, wB);
+        }
         __syncthreads();
+        if (k + 1 < 9) issue(k + 1, 0, tA, wA);          // in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
         // ---- 3. MFMA: out[64 px][32 co of this wave] += slab[64 px][ci of the group] * W[ci][co] ----
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
