@@ -42,44 +42,69 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
     mask[(size_t)i * nb + bj] = bits;
 }
 
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int n, int nb,
-                                                       unsigned long long* __restrict__ removed, uint8_t* __restrict__ keep,
-                                                       int32_t* __restrict__ n_keep) {
-    const int lane = threadIdx.x;
-    for (int w = lane; w < nb; w += 64) removed[w] = 0ull;
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int n, int nb,
+                                                        unsigned long long* __restrict__ removed, uint8_t* __restrict__ keep,
+                                                        int32_t* __restrict__ n_keep) {
+    // 256 threads: every thread owns words of the `removed` bitmap (in LDS); per 64-box tile, wave 0 resolves the
+    // intra-tile dependency chain on the diagonal word (v_readlane broadcast per kept box), publishes the tile's
+    // `kept` word, then all four waves OR the kept rows into the words of the later tiles (independent, pipelined loads)
+    extern __shared__ unsigned long long rem_s[];          // nb words + 1 (kept word of the current tile)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int w = tid; w < nb; w += 256) rem_s[w] = 0ull;
     __syncthreads();
     int total = 0;
+    unsigned long long diag_next = 0ull;                   // wave 0: diagonal word of the next tile, prefetched
+    if (wave == 0 && lane < n) diag_next = mask[(size_t)lane * nb];
     for (int b = 0; b < nb; ++b) {
-        const int i = b * 64 + lane;
-        const unsigned long long diag = (i < n) ? mask[(size_t)i * nb + b] : 0ull;
-        unsigned long long rem = removed[b];
         const int cnt = (n - b * 64) < 64 ? (n - b * 64) : 64;
-        unsigned long long kept = 0ull;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        for (int t = 0; t < cnt; ++t) {
-            if (!((rem >> t) & 1ull)) {
-                kept |= 1ull << t;
-                const unsigned lo = __builtin_amdgcn_readlane(dlo, t), hi = __builtin_amdgcn_readlane(dhi, t);
-                rem |= ((unsigned long long)hi << 32) | lo;
+        if (wave == 0) {
+            const int i = b * 64 + lane;
+            const unsigned long long diag = diag_next;
+            if (b + 1 < nb && i + 64 < n) diag_next = mask[(size_t)(i + 64) * nb + b + 1];
+            else diag_next = 0ull;
+            // scalar chain: `rem` lives in SGPRs (readfirstlane), the branch is a scalar branch
+            const unsigned long long r0 = rem_s[b];
+            unsigned rlo = __builtin_amdgcn_readfirstlane((unsigned)r0), rhi = __builtin_amdgcn_readfirstlane((unsigned)(r0 >> 32));
+            unsigned klo = 0u, khi = 0u;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            for (int t = 0; t < cnt && t < 32; ++t) {
+                if (!((rlo >> t) & 1u)) {
+                    klo |= 1u << t;
+                    rlo |= __builtin_amdgcn_readlane(dlo, t);
+                    rhi |= __builtin_amdgcn_readlane(dhi, t);
+                }
             }
+            for (int t = 32; t < cnt; ++t) {
+                if (!((rhi >> (t - 32)) & 1u)) {
+                    khi |= 1u << (t - 32);
+                    rhi |= __builtin_amdgcn_readlane(dhi, t);
+                }
+            }
+            const unsigned long long kept = ((unsigned long long)khi << 32) | klo;
+            if (i < n) keep[i] = (kept >> lane) & 1ull;
+            if (lane == 0) rem_s[nb] = kept;
+            total += __popcll(kept);
         }
-        if (i < n) keep[i] = (kept >> lane) & 1ull;
-        total += __popcll(kept);
-        // OR the kept rows into the words of the later tiles: every lane owns words w, w+64, ...; the 64 row loads
-        // per word are independent (suppressed rows are masked out, not branched around) so they pipeline
-        for (int w = b + 1 + lane; w < nb; w += 64) {
-            unsigned long long acc = removed[w];
-            const unsigned long long* col = mask + (size_t)(b * 64) * nb + w;
-#pragma unroll 16
-            for (int t = 0; t < 64; ++t) {
-                const unsigned long long v = (t < cnt) ? col[(size_t)t * nb] : 0ull;
-                acc |= ((kept >> t) & 1ull) ? v : 0ull;
+        __syncthreads();
+        const unsigned long long kept = rem_s[nb];
+        // (word, quarter-of-the-rows) work items: 16 independent loads per item, combined with an LDS atomic OR
+        const int nw = nb - b - 1;
+        for (int e = tid; e < nw * 4; e += 256) {
+            const int w = b + 1 + (e >> 2), part = e & 3;
+            const unsigned long long* col = mask + (size_t)(b * 64 + part * 16) * nb + w;
+            unsigned long long acc = 0ull;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int tt = part * 16 + t;
+                const unsigned long long v = (tt < cnt) ? col[(size_t)t * nb] : 0ull;
+                acc |= ((kept >> tt) & 1ull) ? v : 0ull;
             }
-            removed[w] = acc;
+            if (acc) atomicOr(&rem_s[w], acc);
         }
         __syncthreads();
     }
-    if (lane == 0) *n_keep = total;
+    if (tid == 0) *n_keep = total;
+    (void)removed;
 }
 
 }  // namespace
@@ -111,7 +136,7 @@ int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_
     unsigned long long* removed = cv.take<unsigned long long>((size_t)nb + 1);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, stream, (const float4*)boxes, idxs, n, nb,
                        iou_threshold, mask);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, stream, mask, n, nb, removed, keep_mask, n_keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), (size_t)(nb + 1) * 8, stream, mask, n, nb, removed, keep_mask, n_keep);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
