@@ -50,16 +50,25 @@ def init_dist(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local if world > 1 else 0)
-    if world > 1:
+    dist_on = world > 1 or os.environ.get('WT_FORCE_DIST') == '1'       # WT_FORCE_DIST: exercise RCCL with one rank
+    torch.cuda.set_device(local if dist_on else 0)
+    if dist_on:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     return world, rank, local
 
 
+def _dist_on():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except ImportError:
+        return False
+
+
 def barrier_sync(world):
     import torch
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
@@ -81,7 +90,7 @@ def timed_steps(world, run_step, steps, warmup):
     barrier_sync(world)
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,7 +280,7 @@ def main():
             res['cpu_baseline'] = cpu_baseline_e2e(pipe, args.stage == 'e2e')
         metric = 'end-to-end frames/sec (detect+SORT) on 1920x1280 Waymo frames' if args.stage == 'e2e' else \
             'detector frames/sec on 1920x1280 Waymo frames'
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.barrier()
     if rank == 0:
@@ -281,7 +290,7 @@ def main():
                 'config': {'workload': res['workload'], 'stage': args.stage, 'parallelism': 'sequence-shard x%d' % world},
                 'roofline': res.get('roofline'), 'cpu_baseline': res.get('cpu_baseline'), 'extra': res.get('extra')}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -164,3 +164,22 @@ def test_soft_nms_groups_with_nan_negative_and_degenerate_boxes(oracle):
         for g in range(12):
             a, b = int(off[g]), int(off[g]) + int(exp_cnt[g])
             assert np.array_equal(out[a:b], exp[a:b], equal_nan=True), g
+
+
+def test_ensemble_cli_end_to_end(golden_dir, tmp_path):
+    """python -m detnet.ensemble drop-in: files + yml weights in, JSON out (order-insensitive vs the reference rows)."""
+    import yaml
+    from waymo_2d_tracking_amd.detnet import ensemble as E
+    exp = json.load(open(os.path.join(golden_dir, 'ensemble_g2_expected.json')))
+    yml = tmp_path / 'weights.yml'
+    yml.write_text(yaml.safe_dump({golden_dir: {'ensemble_g2_input%d.json' % i: w for i, w in enumerate(exp['weights'])}}))
+    for method in ('soft_nms', 'weighted_fusion'):
+        out = tmp_path / (method + '.json')
+        E.main([str(yml), '-o', str(out), '-m', method, '--iou-thresh', str(exp['iou_thresh']), '--soft-nms-cut',
+                str(exp['soft_nms_cut']), '--min-score', str(exp['min_score'])])
+        got = json.load(open(out))
+        key = lambda r: (r['image_id'], r['category_id'], tuple(r['bbox']))
+        g = sorted(got, key=key); e = sorted(exp['outputs'][method], key=key)
+        assert len(g) == len(e)
+        for a, b in zip(g, e):
+            assert key(a) == key(b) and abs(a['score'] - b['score']) <= 1.0000001e-5
