@@ -29,7 +29,7 @@ UNITS = {
     'det_roialign.hip': [],
     'det_nms.hip': [],
     'det_deform.hip': [],
-    'det_gemm.hip': [],
+    'det_gemm.hip': ['-munsafe-fp-atomics'],
     'det_misc.hip': [],
     'det_backward.hip': ['-munsafe-fp-atomics'],
 }

@@ -19,7 +19,7 @@ constexpr int LD = BK + 2;
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ Bt,
                                                       const float* __restrict__ bias, const float* __restrict__ residual,
-                                                      int relu, int M, int N, int K, float* __restrict__ C) {
+                                                      int relu, int M, int N, int K, float* __restrict__ C, int splitk) {
     constexpr int BM = 32 * WM, BN = 32 * WN;            // 2 waves along each dimension
     constexpr int A_F4 = BM * BK / 4 / 256;              // float4 loads per thread per slab
     constexpr int B_F4 = BN * BK / 4 / 256;
@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order: consecutive workgroups (round-robin over the 8 XCDs) walk N first inside an M stripe
     const int tiles_n = (N + BN - 1) / BN;
-    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    const int tiles = tiles_n * ((M + BM - 1) / BM);
+    const int tile_id = blockIdx.x % tiles, kz = blockIdx.x / tiles;     // split-K: slice kz of the K range
+    const int bm = tile_id / tiles_n, bn = tile_id % tiles_n;
     const int m0 = bm * BM, n0 = bn * BN;
 
     float4 ra[A_F4], rb[B_F4];
@@ -74,8 +76,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nslab = (K + BK - 1) / BK;
-    gload(0);
+    const int nslab_all = (K + BK - 1) / BK;
+    const int per = (nslab_all + splitk - 1) / splitk;
+    const int s_begin = kz * per, s_end = (s_begin + per < nslab_all) ? s_begin + per : nslab_all;
+    const int nslab = s_end - s_begin;
+    if (nslab <= 0) return;
+    const int kbase = s_begin * BK;
+    gload(kbase);
     sstore(0);
     __syncthreads();
     const int arow = wm * 16 * WM + (lane & 15);
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
     const int kl = lane >> 4;
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nslab) gload((s + 1) * BK);
+        if (s + 1 < nslab) gload(kbase + (s + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             float a[WM], b[WN];
@@ -112,6 +119,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * 16 * WM + 16 * i + (lane >> 4) * 4 + r;
                 if (row >= M) continue;
+                if (splitk > 1) {                      // partial sums: C was zeroed, epilogue runs in a second pass
+                    atomicAdd(&C[(size_t)row * N + col], acc[i][j][r]);
+                    continue;
+                }
                 float v = acc[i][j][r] + bv;
                 if (residual) v += residual[(size_t)row * N + col];
                 if (relu) v = fmaxf(v, 0.f);
@@ -134,11 +145,22 @@ extern "C" int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias
     const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (big_tiles >= 192) {
         hipLaunchKernelGGL((gemm_nt_kernel<4, 4>), dim3((unsigned)big_tiles), dim3(256), 0, stream, A, Bt, bias, residual,
-                           relu, M, N, K, C);
+                           relu, M, N, K, C, 1);
     } else {
         const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-        hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), dim3((unsigned)tiles), dim3(256), 0, stream, A, Bt, bias, residual, relu,
-                           M, N, K, C);
+        // few tiles and a long K (the box-head FC: 256 tiles, K = 12544): split K so that >= 2 workgroups share a CU and
+        // hide each other's LDS latency; partial sums meet in C through f32 atomics, the epilogue runs as a second pass
+        int splitk = 1;
+        if (!residual && (N % 4) == 0 && K >= 2048) {
+            while (tiles * splitk < 512 && splitk < 8 && K / (splitk * 2) >= 1024) splitk *= 2;
+        }
+        if (splitk > 1) WT_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream));
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), dim3((unsigned)(tiles * splitk)), dim3(256), 0, stream, A, Bt, bias, residual,
+                           relu, M, N, K, C, splitk);
+        if (splitk > 1 && (bias || relu)) {
+            WT_HIP(hipGetLastError());
+            return wd_bias_relu_f32(C, bias, M, N, relu, stream_);
+        }
     }
     WT_HIP(hipGetLastError());
     return WT_OK;

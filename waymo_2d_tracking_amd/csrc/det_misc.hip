@@ -9,7 +9,7 @@ __global__ __launch_bounds__(256) void bias_relu_kernel(float4* __restrict__ y, 
                                                         int cols4, int relu) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 v = y[i];
-        const float4 b = bias[i % cols4];
+        const float4 b = bias ? bias[i % cols4] : make_float4(0.f, 0.f, 0.f, 0.f);
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         y[i] = v;
@@ -81,7 +81,7 @@ extern "C" int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const fl
 extern "C" int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream) {
     WT_TRY(wt::ensure_device());
     if (m <= 0 || n <= 0) return WT_OK;
-    if ((n & 3) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15)) {
+    if ((n & 3) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) {
         wt::set_error("wd_bias_relu_f32: N must be a multiple of 4 and pointers 16-byte aligned");
         return WT_ERR_INVALID;
     }
