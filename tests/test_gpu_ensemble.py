@@ -183,3 +183,22 @@ def test_ensemble_cli_end_to_end(golden_dir, tmp_path):
         assert len(g) == len(e)
         for a, b in zip(g, e):
             assert key(a) == key(b) and abs(a['score'] - b['score']) <= 1.0000001e-5
+
+
+def test_all_groups_empty_and_single_box(oracle):
+    import ctypes as C
+    from waymo_2d_tracking_amd import _lib
+    for method in (0, 1, 2):
+        d = np.zeros((0, 5)); off = np.zeros(5, np.int64); sizes = np.zeros((4, 2), np.int32)
+        out = np.zeros((1, 5)); cnt = np.full(5, -1, np.int64)
+        _lib.check(_lib.lib().wt_ensemble_groups_host(_lib.ptr(d), _lib.ptr(off), _lib.ptr(sizes), C.c_int64(4), C.c_int(2),
+                                                      C.c_int(method), C.c_double(0.5), C.c_double(0.9), _lib.ptr(out), _lib.ptr(cnt)),
+                   'wt_ensemble_groups_host')
+        assert cnt[:4].tolist() == [0, 0, 0, 0]
+        d = np.array([[0.7, 10.0, 20.0, 30.0, 40.0]]); off = np.array([0, 1], np.int64); sizes = np.array([[1, 0]], np.int32)
+        out = np.zeros((2, 5)); cnt = np.zeros(2, np.int64)
+        _lib.check(_lib.lib().wt_ensemble_groups_host(_lib.ptr(d), _lib.ptr(off), _lib.ptr(sizes), C.c_int64(1), C.c_int(2),
+                                                      C.c_int(method), C.c_double(0.5), C.c_double(0.9), _lib.ptr(out), _lib.ptr(cnt)),
+                   'wt_ensemble_groups_host')
+        exp, ec = oracle.ensemble_groups(d, off, sizes, 2, method, 0.5, 0.9)
+        assert cnt[0] == ec[0] == 1 and np.array_equal(out[:1], exp[:1])

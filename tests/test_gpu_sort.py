@@ -189,3 +189,67 @@ def test_full_size_properties():
     assert np.all(out['bbox'][:, 2] >= 1) and np.all(out['bbox'][:, 3] >= 1)             # utils.py:45
     assert np.all((out['score'] >= 0.2) & (out['score'] <= 1.0))                         # utils.py:49
     assert len(out['frame']) <= packed['x'].size                                         # one row per matched det at most
+
+
+def _pred_from_json(dets):
+    predictions = {}
+    for e in dets:
+        seg, fr, cam = e['image_id'].split('/')
+        predictions.setdefault(seg, {}).setdefault(cam, {}).setdefault(int(fr), []).append(
+            {'bbox': e['bbox'], 'score': e['score'], 'category_id': e['category_id']})
+    return predictions
+
+
+def test_edge_cases_empty_and_single(oracle):
+    """Empty / ragged inputs: streams whose frames are all empty, a single frame, everything filtered by the score
+    threshold, an empty tracker call - same outputs as the oracle, no crash."""
+    from waymo_2d_tracking_amd.tracking.sort.sort import Sort, KalmanBoxTracker
+    # (1) frames exist but carry no detection at all
+    predictions = {'segA': {'FRONT': {100: [], 200: [], 300: []}, 'SIDE_LEFT': {100: []}}}
+    packed = T.pack_streams(predictions)
+    out, births = T.track_packed(packed, [0.01, 0.01, 1.0, 0.0], 2, 0, [0.0] * 4)
+    assert births == 0 and len(out['frame']) == 0
+    # (2) one frame, one detection; (3) all detections below the threshold
+    one = {'s': {'FRONT': {7: [{'bbox': [10, 20, 30, 40], 'score': 0.9, 'category_id': 2}]}}}
+    packed = T.pack_streams(one)
+    out, births = T.track_packed(packed, [0.01, 0.01, 1.0, 0.0], 2, 0, [0.0] * 4)
+    ref = oracle.track_streams(packed, 2, 0, [0.0] * 4, [0.01, 0.01, 1.0, 0.0])
+    assert births == 1 and np.array_equal(out['bbox'], ref['bbox']) and out['object_id'].tolist() == [1]
+    out, births = T.track_packed(packed, [0.01, 0.01, 1.0, 0.0], 2, 0, [0.95] * 4)
+    assert births == 0 and len(out['frame']) == 0
+    # (4) Sort.update with empty detections on a fresh and on a populated tracker
+    KalmanBoxTracker.count = 0
+    s = Sort(max_age=1, min_hits=0)
+    assert s.update(np.array([], dtype=np.float32), 0.3).shape == (0, 6)
+    r = s.update(np.array([[0, 0, 10, 10, 1.0], [50, 50, 80, 90, 0.5]], dtype=np.float32), 0.3)
+    assert r.shape == (2, 6) and sorted(r[:, 4].tolist()) == [1.0, 2.0]
+    assert s.update(np.array([], dtype=np.float32), 0.3).shape == (0, 6)
+    assert s.update(np.array([], dtype=np.float32), 0.3).shape == (0, 6)          # tracks reaped (max_age 1)
+    ids, _, _ = s.state()
+    assert len(ids) == 0
+
+
+def test_large_frames_use_the_global_cost_path(oracle):
+    """Frames with several hundred boxes of one class: the N x T cost matrix exceeds the LDS budget (global scratch),
+    the zero bitmaps need > 1 word per row, the per-object Sort grows its device state - still identical to the oracle."""
+    from waymo_2d_tracking_amd import synthetic as syn
+    rng = np.random.default_rng(9)
+    d = syn.stream_detections(rng, 12, 420, 'FRONT', clutter=0.05)
+    d['cat'][:] = 1                                     # one class: N ~ 400 per frame, T up to ~ 3 N
+    dets = syn.detections_json([('seg', 'FRONT', d)])
+    packed = T.pack_streams(_pred_from_json(dets))
+    ithr, sthr = [0.05, 0.01, 1.0, 0.0], [0.0] * 4
+    out, births = T.track_packed(packed, ithr, 2, 0, sthr)
+    ref = oracle.track_streams(packed, 2, 0, sthr, ithr)
+    assert births == ref['n_births']
+    assert np.array_equal(out['object_id'], ref['object_id']) and np.array_equal(out['bbox'], ref['bbox'])
+    # the per-object API on the same data (device state grows past its initial 256 slots)
+    from waymo_2d_tracking_amd.tracking.sort.sort import Sort, KalmanBoxTracker
+    KalmanBoxTracker.count = 0
+    s = Sort(max_age=2, min_hits=0)
+    o = oracle.Sort(2, 0)
+    for f in range(4):
+        sel = d['frame'] == f
+        arr = np.stack([d['x'][sel], d['y'][sel], d['x'][sel] + d['w'][sel], d['y'][sel] + d['h'][sel], d['score'][sel]], 1).astype(np.float32)
+        a, b = s.update(arr, 0.05), o.update(arr, 0.05)
+        assert a.shape == b.shape and np.array_equal(a[:, :5], b[:, :5])
