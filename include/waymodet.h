@@ -67,6 +67,22 @@ int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias, const flo
 int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const float* beta, int n, int hw, int c, int groups,
                                float eps, int relu, void* stream);
 
+/* Fused image pre-processing in front of the detector (one HBM pass): replaces TTA.pre_process
+ * (detnet/nn/tta.py:179-190 ResizeTTA = F.interpolate(scale_factor, bilinear, align_corners=False); :147-156
+ * HFlipTTA / VFlipTTA = torch.flip), Detectron2Det.forward's RGB->BGR swap (detnet/nn/detectron2_det/__init__.py:70-74)
+ * and detectron2's (x - PIXEL_MEAN) / PIXEL_STD + zero padding to a multiple of `divisor` (size_divisibility 32).
+ *   src        : DEVICE pointer; WD_LAYOUT_NCHW_F32 = (N,3,H,W) float32 0..255 (what Detectron2Det.predict receives),
+ *                WD_LAYOUT_NHWC_U8 = (N,H,W,3) uint8 (decoded camera frames)
+ *   order of operations = the reference's: resize by `scale` (1.0 = none), flips, channel swap (swap_rb != 0),
+ *                normalisation with mean3 / std3 (HOST pointers, indexed by OUTPUT channel; NULL = 0 / 1), padding
+ *   out        : (N, Hp, Wp, 3) NHWC float32, Ho = floor(H*scale), Hp = ceil(Ho/divisor)*divisor (same for W);
+ *                wd_preprocess_out_shape returns Ho, Wo, Hp, Wp (host-only helper, no GPU needed). */
+#define WD_LAYOUT_NCHW_F32 0
+#define WD_LAYOUT_NHWC_U8 1
+int wd_preprocess_out_shape(int h, int w, double scale, int divisor, int* ho, int* wo, int* hp, int* wp);
+int wd_preprocess_f32(const void* src, int src_layout, int batch, int h, int w, double scale, int hflip, int vflip,
+                      int swap_rb, const float* mean3, const float* std3, int divisor, float* out, void* stream);
+
 /* ---- backward (training fwd+bwd) ---------------------------------------------------
  * ROIPooler backward: grad_out (R, pooled, pooled, C) is scattered (+=) into grad_feats[l] (same shapes as the
  * forward feats; the caller zero-initialises them).  grad_feats: HOST array of DEVICE pointers. */

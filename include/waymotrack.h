@@ -61,6 +61,22 @@ int wt_sort_num_tracks(const wt_sort* s);
 /* Debug/test hook: current track list in list order (ids, state x[7], covariance P[49], row-major). */
 int wt_sort_state_host(wt_sort* s, int cap, int64_t* ids, double* x7, double* P49, int* n_tracks);
 
+/* MultiClassTrackerSort(max_age, min_hits) - tracking/sort/tracker_sort.py:10-51: one Sort per class, created the first
+ * time the class is seen; every known class is updated once per call, in first-seen order.
+ *   dets6          : (n,6) float64 rows [x1,y1,x2,y2,confidence,class] (class = integer >= 1), cast to float32 like
+ *                    np.array(..., dtype=np.float32) (:45)
+ *   iou_thresholds : iou_thresholds[class-1] (:49); a class beyond n_thresholds is WT_ERR_INVALID (IndexError there)
+ *   out6           : rows [x1,y1,x2,y2,id+1,confidence] of all classes, grouped by class in first-seen order;
+ *   out_classes[k] / out_counts[k] : class id and row count of group k (k < *n_classes <= class_cap)
+ * wt_mct_tracker returns the class's Sort (borrowed; NULL if the class has not been seen) for wt_sort_state_host. */
+typedef struct wt_mct wt_mct;
+int wt_mct_create(int max_age, int min_hits, wt_idctr* ctr, wt_mct** out);
+void wt_mct_destroy(wt_mct* m);
+int wt_mct_num_classes(const wt_mct* m);
+wt_sort* wt_mct_tracker(wt_mct* m, int class_id);
+int wt_mct_track_host(wt_mct* m, const double* dets6, int n, const double* iou_thresholds, int n_thresholds,
+                      double* out6, int cap, int32_t* out_classes, int32_t* out_counts, int class_cap, int* n_classes);
+
 /* associate_detections_to_trackers(detections, trackers, iou_threshold) - tracking/sort/sort.py:193-230
  * (IoU matrix :33-47,201-205 + sklearn 0.22.2 linear_assignment :206 + threshold filter :218-224).
  * dets5 (n,5) f32, trks4 (t,4) f64.  matches: (det,trk) pairs sorted by det; unmatched lists in the

@@ -68,16 +68,26 @@ def test_tta_x15_hflip_roundtrip(models):
     """--tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image; cx is mirrored back."""
     from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
     from waymo_2d_tracking_amd.detnet.nn.tta import TTA
+    from waymo_2d_tracking_amd.detnet.nn import ops
     m = Detectron2Det(seed=1).eval().cuda()
     x = torch.randint(0, 256, (1, 3, 96, 128)).float().cuda()
-    big = torch.flip(torch.nn.functional.interpolate(x, scale_factor=1.5, mode='bilinear', align_corners=False), [3])
-    direct = m.predict(big)
+    direct = m.predict(x, 1.5, True, False)                 # fused pre-processing: resize x1.5 + hflip inside the kernel
+    assert m.last_input_size == (144, 192)
     via = TTA(m, ['x1.5', 'hflip']).predict(x)
+    n = 0
     for a, b in zip(direct[0], via[0]):
         assert a.shape == b.shape
+        n += len(a)
         if len(a):
             np.testing.assert_allclose(1 - a[:, 1], b[:, 1], atol=1e-6)
             np.testing.assert_allclose(a[:, [0, 2, 3, 4]], b[:, [0, 2, 3, 4]], atol=1e-6)
+    # the un-fused route (torch resize + flip, then the detector) sees the same image up to fp32 rounding of the
+    # bilinear weights (tests/test_gpu_detops.py pins the fused kernel to the reference's TTA.pre_process output)
+    big = torch.flip(torch.nn.functional.interpolate(x, scale_factor=1.5, mode='bilinear', align_corners=False), [3])
+    xn, _ = ops.preprocess(x, 1.5, True, False, False, None, None, 32)
+    assert float((xn[:, :, :144, :192] - big).abs().max()) <= 1e-3
+    unfused = m.predict(big)
+    assert abs(sum(len(a) for a in unfused[0]) - n) <= max(2, n // 10)
 
 
 def test_training_step_losses_and_gradients():

@@ -1,5 +1,7 @@
 """Detector custom ops (HIP, through the C ABI) against the PyTorch restatement in oracle/detops_ref.py.
 float32 kernels vs float64 references: tolerances stated per test (north_star: 1e-4 on boxes/scores)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -176,3 +178,87 @@ def test_roi_pool_backward_vs_autograd_reference():
         a = fg[l].grad.cpu().double()
         b = fr[l].grad if fr[l].grad is not None else torch.zeros_like(a)      # level without ROIs
         assert (a - b).abs().max().item() < 1e-4 * (b.abs().max().item() + 1e-6) + 1e-6, l
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fused pre-processing kernel (rows a21 / a16): resize + flips + BGR + normalise + pad
+from waymo_2d_tracking_amd.detnet.nn import ops  # noqa: E402
+
+
+def _g7(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'tta_g7.npz'))
+    return g, len([k for k in g.files if k.endswith('_spec')])
+
+
+def _parse_spec(spec):
+    scale, hf, vf = 1.0, False, False
+    for a in spec.split(','):
+        if a.startswith('x'):
+            scale = float(a[1:])
+        hf |= a == 'hflip'
+        vf |= a == 'vflip'
+    return scale, hf, vf
+
+
+def test_preprocess_matches_reference_tta_fixture(golden_dir):
+    """G7: wd_preprocess_f32 (no swap / normalisation) == the reference's TTA.pre_process output (F.interpolate
+    bilinear align_corners=False, torch.flip), tolerance 1e-4 on 0..255 values; the padding is exactly zero."""
+    g, n = _g7(golden_dir)
+    for ci in range(n):
+        spec = str(g['c%d_spec' % ci])
+        scale, hf, vf = _parse_spec(spec)
+        x = torch.from_numpy(g['c%d_x' % ci]).cuda()
+        want = g['c%d_pre' % ci]
+        for layout in ('f32', 'u8'):
+            src = x if layout == 'f32' else x.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+            out, (ho, wo) = ops.preprocess(src, scale, hf, vf, swap_rb=False, mean=None, std=None, divisor=32)
+            assert (ho, wo) == want.shape[2:], spec
+            assert out.shape[2] % 32 == 0 and out.shape[3] % 32 == 0 and out.is_contiguous(memory_format=torch.channels_last)
+            got = out.cpu().numpy()
+            np.testing.assert_allclose(got[:, :, :ho, :wo], want, rtol=0, atol=1e-4, err_msg='%s %s' % (spec, layout))
+            assert not got[:, :, ho:, :].any() and not got[:, :, :, wo:].any()
+
+
+def test_preprocess_normalise_swap_matches_model_preprocess():
+    """Fused kernel == the torch restatement used by the training path (CascadeRCNN.preprocess after the RGB->BGR swap),
+    bit for bit when there is no resize (same subtraction / division per element)."""
+    from waymo_2d_tracking_amd.detnet.nn.cascade_rcnn import PIXEL_MEAN, PIXEL_STD
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (2, 3, 70, 90), generator=g).float().cuda()
+    out, (ho, wo) = ops.preprocess(x, 1.0, False, False, True, PIXEL_MEAN, PIXEL_STD, 32)
+    bgr = x[:, [2, 1, 0]]
+    mean = torch.tensor(PIXEL_MEAN, device='cuda').view(1, 3, 1, 1)
+    std = torch.tensor(PIXEL_STD, device='cuda').view(1, 3, 1, 1)
+    want = torch.nn.functional.pad((bgr - mean) / std, (0, 96 - 90, 0, 96 - 70))
+    assert (ho, wo) == (70, 90) and out.shape == want.shape
+    assert torch.equal(out, want)
+
+
+def test_preprocess_full_size_properties():
+    """1920x1280 (BASELINE.json frame size), --tta x1.5,hflip: size-independent properties.  (i) hflip of the output
+    == output of the hflip-free call mirrored; (ii) a constant image stays constant under bilinear resize;
+    (iii) u8 and f32 sources agree exactly; (iv) scale 1 without flips is a pure layout change."""
+    g = torch.Generator().manual_seed(11)
+    u8 = torch.randint(0, 256, (1, 1280, 1920, 3), generator=g, dtype=torch.uint8).cuda()
+    f32 = u8.permute(0, 3, 1, 2).float().contiguous()
+    a, (ho, wo) = ops.preprocess(f32, 1.5, True, False, False, None, None, 32)
+    b, _ = ops.preprocess(f32, 1.5, False, False, False, None, None, 32)
+    assert (ho, wo) == (1920, 2880) and a.shape == (1, 3, 1920, 2880)
+    assert torch.equal(a, torch.flip(b, [3]))
+    c, _ = ops.preprocess(u8, 1.5, True, False, False, None, None, 32)
+    assert torch.equal(a, c)
+    const = torch.full((1, 3, 1280, 1920), 77.0, device='cuda')
+    d, _ = ops.preprocess(const, 1.5, True, True, False, None, None, 32)
+    assert float((d - 77.0).abs().max()) <= 1e-4
+    e, _ = ops.preprocess(u8, 1.0, False, False, False, None, None, 32)
+    assert torch.equal(e, f32)
+    ref = torch.flip(torch.nn.functional.interpolate(f32, scale_factor=1.5, mode='bilinear', align_corners=False), [3])
+    assert float((a - ref).abs().max()) <= 1e-3          # torch's own GPU kernel, fp32 on 0..255 values
+
+
+def test_preprocess_rejects_bad_arguments():
+    x = torch.zeros((1, 3, 8, 8), device='cuda')
+    with pytest.raises(RuntimeError):
+        ops.preprocess(x, 0.0)
+    with pytest.raises(RuntimeError):
+        ops.preprocess(x, 1.0, divisor=6)

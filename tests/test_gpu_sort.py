@@ -253,3 +253,38 @@ def test_large_frames_use_the_global_cost_path(oracle):
         arr = np.stack([d['x'][sel], d['y'][sel], d['x'][sel] + d['w'][sel], d['y'][sel] + d['h'][sel], d['score'][sel]], 1).astype(np.float32)
         a, b = s.update(arr, 0.05), o.update(arr, 0.05)
         assert a.shape == b.shape and np.array_equal(a[:, :5], b[:, :5])
+
+
+def test_mct_c_abi_order_and_errors():
+    """wt_mct_* (tracker_sort.py:22-51): classes come back in first-seen order, known classes are updated every frame
+    even without detections, rows equal independent per-class Sorts sharing one ID counter, and a class without an
+    iou threshold is an error (IndexError in the reference)."""
+    import ctypes as C
+    from waymo_2d_tracking_amd import _lib
+    from waymo_2d_tracking_amd.tracking.sort.sort import KalmanBoxTracker, Sort
+    from waymo_2d_tracking_amd.tracking.sort.tracker_sort import MultiClassTrackerSort
+    rng = np.random.default_rng(3)
+    thr = [0.01, 0.01, 1.0, 0.0]
+
+    def frame(n):
+        xy = rng.uniform(0, 1500, (n, 2)); wh = rng.uniform(20, 200, (n, 2))
+        return np.concatenate((xy, xy + wh, rng.uniform(0.1, 1, (n, 1)), rng.choice([4, 2, 1], (n, 1))), 1)
+
+    frames = [frame(12), frame(0), frame(7), frame(15)]
+    frames[0][:, 5] = [4] * 5 + [2] * 4 + [1] * 3                       # first-seen order 4, 2, 1
+    KalmanBoxTracker.count = 0
+    mct = MultiClassTrackerSort(max_age=2, min_hits=0)
+    got = [mct.track(f.tolist(), thr) for f in frames]
+    assert list(mct.trackers) == [4, 2, 1] and all(list(g) == [4, 2, 1] for g in got)
+    n_ids = KalmanBoxTracker.count
+    KalmanBoxTracker.count = 0
+    sorts = {c: Sort(2, 0) for c in (4, 2, 1)}
+    for f, g in zip(frames, got):
+        for c in (4, 2, 1):
+            want = sorts[c].update(np.asarray([r[:5] for r in f.tolist() if r[5] == c], dtype=np.float32), thr[c - 1])
+            assert np.array_equal(g[c], want)
+    assert KalmanBoxTracker.count == n_ids > 0
+    bad = frame(3); bad[:, 5] = 7
+    with pytest.raises(RuntimeError):
+        mct.track(bad.tolist(), thr)
+    assert _lib.lib().wt_mct_tracker(mct._h, C.c_int(3)) is None

@@ -70,6 +70,10 @@ def lib():
         _lib.wt_idctr_set.argtypes = [C.c_void_p, C.c_int64]
         _lib.wt_idctr_destroy.argtypes = [C.c_void_p]
         _lib.wt_sort_destroy.argtypes = [C.c_void_p]
+        _lib.wt_mct_destroy.argtypes = [C.c_void_p]
+        _lib.wt_mct_tracker.restype = C.c_void_p
+        _lib.wt_mct_tracker.argtypes = [C.c_void_p, C.c_int]
+        _lib.wt_sort_num_tracks.argtypes = [C.c_void_p]
         for name in ('wt_track_streams_workspace', 'wt_ensemble_groups_workspace'):
             getattr(_lib, name).restype = C.c_size_t
         for name in ('wd_workspace_bytes',):

@@ -53,8 +53,8 @@ class DetectTrackPipeline(object):
 
     def detect_frame(self, f):
         """Frame f (camera-major order) -> wire-format detections written into slots [f*100, f*100+100)."""
-        img = self.frames[f].permute(2, 0, 1).unsqueeze(0).float()           # ToTensor(scaling=False): 0..255 RGB
-        (boxes, scores, classes), = self.model.predict_device(img)
+        # decoded uint8 HWC RGB frame -> fused pre-processing kernel (ToTensor(scaling=False) + BGR + normalise + pad)
+        (boxes, scores, classes), = self.model.predict_device(self.frames[f:f + 1])
         xywh, score, cat = detections_to_wire(boxes, scores, classes, self.w, self.h)
         k = xywh.shape[0]
         a = f * SLOTS

@@ -31,6 +31,7 @@ UNITS = {
     'det_deform.hip': [],
     'det_gemm.hip': ['-munsafe-fp-atomics'],
     'det_misc.hip': [],
+    'det_preprocess.hip': ['-ffp-contract=off'],
     'det_backward.hip': ['-munsafe-fp-atomics'],
 }
 

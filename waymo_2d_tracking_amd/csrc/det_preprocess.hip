@@ -1,0 +1,142 @@
+// Fused image pre-processing in front of the detector (SURVEY rows a21 + a16, §8f rank 3): ONE pass over HBM replaces
+//   TTA.pre_process            detnet/nn/tta.py:179-190 (ResizeTTA: F.interpolate bilinear, align_corners=False),
+//                              detnet/nn/tta.py:147-156 (HFlipTTA / VFlipTTA: torch.flip)
+//   Detectron2Det.forward      detnet/nn/detectron2_det/__init__.py:70-74 (RGB -> BGR)
+//   detectron2 preprocess_image (x - PIXEL_MEAN) / PIXEL_STD, ImageList.from_tensors zero padding to a multiple of 32
+// and writes the NHWC tensor the stem convolution reads.  HBM bound: reads H*W*3 source elements once (the 4 bilinear
+// corners of neighbouring outputs hit L1/L2), writes Hp*Wp*3 floats once.
+//
+// Work item = 4 consecutive output pixels (12 floats, three float4 stores; a wavefront covers 3 KiB contiguous) so the
+// bilinear coordinates are computed once per pixel and the planar / interleaved source reads stay coalesced.  Bilinear arithmetic follows ATen's
+// upsample_bilinear2d (area_pixel_compute_source_index, float accumulation type).
+#include "common.h"
+#include "../../include/waymodet.h"
+
+namespace {
+
+struct PreArgs {
+    int n, h, w;            // source
+    int ho, wo;             // resized (valid) extent
+    int hp, wp;             // padded output extent
+    float rh, rw;           // source step per output pixel (1/scale)
+    int resize, hflip, vflip, swap_rb;
+    float mean[3], inv_or_std[3];
+};
+
+template <typename T, bool HWC>
+__device__ __forceinline__ float src_at(const T* __restrict__ src, const PreArgs& a, int n, int c, int y, int x) {
+    if (HWC) return (float)src[(((size_t)n * a.h + y) * a.w + x) * 3 + c];
+    return (float)src[(((size_t)n * 3 + c) * a.h + y) * a.w + x];
+}
+
+// ATen computes the source coordinate scale * (dst + 0.5) - 0.5 inside a kernel compiled with FMA contraction; the
+// fused form is reproduced explicitly (at x ~ 1900 one ulp of the coordinate moves a 0..255 value by up to 0.03).
+__device__ __forceinline__ void src_coord(float r, int dst, int size, int resize, int& i0, int& i1, float& l) {
+    if (!resize) { i0 = i1 = dst; l = 0.f; return; }
+    float s = fmaf(r, (float)dst + 0.5f, -0.5f);
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i0 = i0 > size - 1 ? size - 1 : i0;
+    i1 = i0 + (i0 < size - 1 ? 1 : 0);
+    l = s - (float)i0;
+}
+
+template <typename T, bool HWC>
+__global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ src, PreArgs a, float* __restrict__ out) {
+    // work item = 4 consecutive output pixels of one row = 12 floats = three float4 stores (Wp is a multiple of 4)
+    const int row_q = a.wp / 4;
+    const long total = (long)a.n * a.hp * row_q;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % row_q);
+        const long t = i / row_q;
+        const int oy = (int)(t % a.hp), n = (int)(t / a.hp);
+        float v[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) v[j] = 0.f;
+        if (oy < a.ho && q * 4 < a.wo) {
+            int y0, y1;
+            float ly;
+            src_coord(a.rh, a.vflip ? a.ho - 1 - oy : oy, a.h, a.resize, y0, y1, ly);
+            const float hy = 1.f - ly;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int ox = q * 4 + p;
+                if (ox >= a.wo) continue;
+                int x0, x1;
+                float lx;
+                src_coord(a.rw, a.hflip ? a.wo - 1 - ox : ox, a.w, a.resize, x0, x1, lx);
+                const float hx = 1.f - lx;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const int ci = a.swap_rb ? 2 - co : co;
+                    float val;
+                    if (a.resize) {
+                        const float p00 = src_at<T, HWC>(src, a, n, ci, y0, x0), p01 = src_at<T, HWC>(src, a, n, ci, y0, x1);
+                        const float p10 = src_at<T, HWC>(src, a, n, ci, y1, x0), p11 = src_at<T, HWC>(src, a, n, ci, y1, x1);
+                        val = hy * (hx * p00 + lx * p01) + ly * (hx * p10 + lx * p11);
+                    } else {
+                        val = src_at<T, HWC>(src, a, n, ci, y0, x0);
+                    }
+                    v[p * 3 + co] = (val - a.mean[co]) / a.inv_or_std[co];
+                }
+            }
+        }
+        float4* o = reinterpret_cast<float4*>(out) + i * 3;
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o[1] = make_float4(v[4], v[5], v[6], v[7]);
+        o[2] = make_float4(v[8], v[9], v[10], v[11]);
+    }
+}
+
+}  // namespace
+
+extern "C" int wd_preprocess_out_shape(int h, int w, double scale, int divisor, int* ho, int* wo, int* hp, int* wp) {
+    if (h <= 0 || w <= 0 || !(scale > 0.0) || divisor <= 0 || !ho || !wo || !hp || !wp) {
+        wt::set_error("wd_preprocess_out_shape: invalid arguments (h=%d w=%d scale=%g divisor=%d)", h, w, scale, divisor);
+        return WT_ERR_INVALID;
+    }
+    // F.interpolate(scale_factor=s): output size = floor(float(input_size) * s), computed in double
+    *ho = scale == 1.0 ? h : (int)((double)h * scale);
+    *wo = scale == 1.0 ? w : (int)((double)w * scale);
+    if (*ho <= 0 || *wo <= 0) {
+        wt::set_error("wd_preprocess_out_shape: scale %g collapses a %dx%d image", scale, h, w);
+        return WT_ERR_INVALID;
+    }
+    *hp = (*ho + divisor - 1) / divisor * divisor;
+    *wp = (*wo + divisor - 1) / divisor * divisor;
+    return WT_OK;
+}
+
+extern "C" int wd_preprocess_f32(const void* src, int src_layout, int batch, int h, int w, double scale, int hflip, int vflip,
+                                 int swap_rb, const float* mean3, const float* std3, int divisor, float* out, void* stream_) {
+    WT_TRY(wt::ensure_device());
+    if (batch <= 0) return WT_OK;
+    PreArgs a;
+    WT_TRY(wd_preprocess_out_shape(h, w, scale, divisor, &a.ho, &a.wo, &a.hp, &a.wp));
+    if (!src || !out || (src_layout != WD_LAYOUT_NCHW_F32 && src_layout != WD_LAYOUT_NHWC_U8) || (divisor & 3) ||
+        ((uintptr_t)out & 15)) {
+        wt::set_error("wd_preprocess_f32: invalid arguments (layout=%d divisor=%d; divisor must be a multiple of 4, out 16-byte aligned)",
+                      src_layout, divisor);
+        return WT_ERR_INVALID;
+    }
+    a.n = batch; a.h = h; a.w = w;
+    a.resize = scale != 1.0;
+    // ATen: the user-provided scale_factor is used for the coordinate map (recompute_scale_factor unset): 1/scale
+    a.rh = (float)(1.0 / scale);
+    a.rw = (float)(1.0 / scale);
+    a.hflip = hflip != 0; a.vflip = vflip != 0; a.swap_rb = swap_rb != 0;
+    for (int c = 0; c < 3; ++c) {
+        a.mean[c] = mean3 ? mean3[c] : 0.f;
+        a.inv_or_std[c] = std3 ? std3[c] : 1.f;
+    }
+    const long total = (long)batch * a.hp * (a.wp / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (src_layout == WD_LAYOUT_NCHW_F32)
+        hipLaunchKernelGGL((preprocess_kernel<float, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)src, a, out);
+    else
+        hipLaunchKernelGGL((preprocess_kernel<uint8_t, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)src, a, out);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}

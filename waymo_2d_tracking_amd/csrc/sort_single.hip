@@ -422,3 +422,93 @@ int wt_associate_host(const float* dets5, int n, const double* trks4, int t, dou
 }
 
 }  // extern "C"
+
+// ---- MultiClassTrackerSort (tracking/sort/tracker_sort.py:10-51): one Sort per class, created at first sight ----
+
+struct wt_mct {
+    int max_age = 1, min_hits = 0;
+    wt_idctr* ctr = nullptr;
+    wt_idctr* own = nullptr;
+    std::vector<int> classes;          // first-seen order == dict order of self.trackers
+    std::vector<wt_sort*> sorts;
+    std::vector<float> rows;
+};
+
+extern "C" {
+
+int wt_mct_create(int max_age, int min_hits, wt_idctr* ctr, wt_mct** out) {
+    if (!out) return WT_ERR_INVALID;
+    *out = nullptr;
+    WT_TRY(wt::ensure_device());
+    wt_mct* m = new wt_mct;
+    m->max_age = max_age; m->min_hits = min_hits;
+    m->own = ctr ? nullptr : wt_idctr_create(0);
+    m->ctr = ctr ? ctr : m->own;
+    *out = m;
+    return WT_OK;
+}
+
+void wt_mct_destroy(wt_mct* m) {
+    if (!m) return;
+    for (wt_sort* s : m->sorts) wt_sort_destroy(s);
+    if (m->own) wt_idctr_destroy(m->own);
+    delete m;
+}
+
+int wt_mct_num_classes(const wt_mct* m) { return m ? (int)m->classes.size() : 0; }
+
+wt_sort* wt_mct_tracker(wt_mct* m, int class_id) {
+    if (!m) return nullptr;
+    for (size_t k = 0; k < m->classes.size(); ++k)
+        if (m->classes[k] == class_id) return m->sorts[k];
+    return nullptr;
+}
+
+int wt_mct_track_host(wt_mct* m, const double* dets6, int n, const double* iou_thresholds, int n_thresholds,
+                      double* out6, int cap, int32_t* out_classes, int32_t* out_counts, int class_cap, int* n_classes) {
+    if (!m || n < 0 || (n > 0 && !dets6) || !iou_thresholds || !n_classes || (cap > 0 && !out6)) {
+        wt::set_error("wt_mct_track_host: bad argument");
+        return WT_ERR_INVALID;
+    }
+    *n_classes = 0;
+    // tracker_sort.py:28-35: bucket by class; a new class gets its Sort the first time it is seen (detection order)
+    for (int i = 0; i < n; ++i) {
+        const int cls = (int)dets6[(size_t)i * 6 + 5];
+        if (cls < 1 || cls > n_thresholds) {
+            wt::set_error("wt_mct_track_host: class %d has no iou threshold (iou_thresholds[class-1], %d given)", cls, n_thresholds);
+            return WT_ERR_INVALID;
+        }
+        bool known = false;
+        for (int c : m->classes) known |= c == cls;
+        if (!known) {
+            wt_sort* s = nullptr;
+            WT_TRY(wt_sort_create(m->max_age, m->min_hits, m->ctr, &s));
+            m->classes.push_back(cls);
+            m->sorts.push_back(s);
+        }
+    }
+    if ((int)m->classes.size() > class_cap || !out_classes || !out_counts) {
+        wt::set_error("wt_mct_track_host: %d classes do not fit class_cap %d", (int)m->classes.size(), class_cap);
+        return WT_ERR_CAPACITY;
+    }
+    // :41-49: every known class, in first-seen order, is updated once per frame (empty array when it has no detections)
+    int written = 0;
+    for (size_t k = 0; k < m->classes.size(); ++k) {
+        const int cls = m->classes[k];
+        m->rows.clear();
+        for (int i = 0; i < n; ++i) {
+            if ((int)dets6[(size_t)i * 6 + 5] != cls) continue;
+            for (int j = 0; j < 5; ++j) m->rows.push_back((float)dets6[(size_t)i * 6 + j]);   // np.array(..., dtype=np.float32)
+        }
+        int k_out = 0;
+        WT_TRY(wt_sort_update_host(m->sorts[k], m->rows.data(), (int)(m->rows.size() / 5), iou_thresholds[cls - 1],
+                                   out6 + (size_t)written * 6, cap - written, &k_out));
+        out_classes[k] = cls;
+        out_counts[k] = k_out;
+        written += k_out;
+    }
+    *n_classes = (int)m->classes.size();
+    return WT_OK;
+}
+
+}  // extern "C"

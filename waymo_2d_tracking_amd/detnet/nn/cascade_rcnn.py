@@ -334,7 +334,12 @@ class CascadeRCNN(nn.Module):
         `proposals` overrides the RPN output and `intermediates` (a dict) receives feature maps / stage outputs:
         both are test hooks."""
         img_h, img_w = image_bgr.shape[2], image_bgr.shape[3]
-        feats = self.backbone(self.preprocess(image_bgr))
+        return self.forward_normalized(self.preprocess(image_bgr), img_h, img_w, proposals, intermediates)
+
+    def forward_normalized(self, x, img_h, img_w, proposals=None, intermediates=None):
+        """Same, from the normalised / padded NHWC tensor that ops.preprocess (the fused HIP pre-processing kernel)
+        or self.preprocess produce; (img_h, img_w) = the valid (unpadded) extent."""
+        feats = self.backbone(x)
         if proposals is None:
             proposals = self.rpn(feats, img_h, img_w)
         scales = [1.0 / s for s in (4, 8, 16, 32)]

@@ -9,7 +9,8 @@ import numpy as np
 import torch
 from torch.nn import Module
 
-from .cascade_rcnn import CascadeRCNN
+from . import ops
+from .cascade_rcnn import CascadeRCNN, PIXEL_MEAN, PIXEL_STD
 
 WAYMO_CLASSNAMES = ('vehicle', 'pedestrian', 'sign', 'cyclist')      # category ids 1..4 (waymo_to_coco.py:19,36)
 
@@ -29,10 +30,15 @@ class Detectron2Det(Module):
         return x[:, [2, 1, 0]]
 
     @torch.no_grad()
-    def predict_device(self, x):
-        """(B,3,H,W) RGB 0..255 on the model's device -> list of (boxes xyxy px, scores, classes) device tensors."""
-        x = self(x.to(next(self.parameters())))
-        return [self.model(x[i:i + 1]) for i in range(x.shape[0])]
+    def predict_device(self, x, scale=1.0, hflip=False, vflip=False):
+        """(B,3,H,W) float RGB 0..255 or (B,H,W,3) uint8 RGB -> list of (boxes xyxy px, scores, classes) device tensors.
+        One fused HIP kernel does TTA.pre_process (tta.py:147-190: resize by `scale`, flips), the RGB->BGR swap of
+        forward() (:70-74), detectron2's normalisation and the padding to a multiple of 32; boxes are in pixels of the
+        transformed (resized / flipped) image, like the reference's detector sees it."""
+        dev = next(self.parameters()).device
+        xn, (ho, wo) = ops.preprocess(x.to(dev), scale, hflip, vflip, True, PIXEL_MEAN, PIXEL_STD, 32)
+        self.last_input_size = (ho, wo)
+        return [self.model.forward_normalized(xn[i:i + 1], ho, wo) for i in range(xn.shape[0])]
 
     def criterion(self, args=None):
         """detectron2_det/__init__.py:141-142"""
@@ -51,14 +57,18 @@ class Detectron2Det(Module):
                 total[k] = total.get(k, 0) + v / x.shape[0]
         return total
 
-    def predict(self, x):
+    def predict(self, x, scale=1.0, hflip=False, vflip=False):
+        """detectron2_det/__init__.py:76-139.  `scale / hflip / vflip` (extension) fold TTA.pre_process into the fused
+        pre-processing kernel; the returned boxes are normalised in the transformed image, as if the reference's
+        predict had been handed TTA.pre_process(x)."""
         single = False
         if not torch.is_tensor(x):                              # PIL image (:103-107)
             x = torch.as_tensor(np.float32(x).transpose(2, 0, 1)).unsqueeze(0)
             single = True
-        h, w = x.shape[-2:]
+        results = self.predict_device(x, scale, hflip, vflip)
+        h, w = self.last_input_size
         output = []
-        for boxes, scores, classes in self.predict_device(x):
+        for boxes, scores, classes in results:
             bbox_cls = []
             if scores.numel():
                 bx = boxes.clone()

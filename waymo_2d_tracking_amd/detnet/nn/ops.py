@@ -168,6 +168,36 @@ def groupnorm_relu_(x, weight, bias, groups, eps=1e-5, relu=True):
     return x
 
 
+def preprocess_out_shape(h, w, scale=1.0, divisor=32):
+    """(Ho, Wo, Hp, Wp) of preprocess(): resized extent and the extent padded to a multiple of `divisor`."""
+    o = [C.c_int(0) for _ in range(4)]
+    _lib.check(_lib.lib().wd_preprocess_out_shape(C.c_int(h), C.c_int(w), C.c_double(scale), C.c_int(divisor),
+                                                  *[C.byref(v) for v in o]), 'wd_preprocess_out_shape')
+    return tuple(v.value for v in o)
+
+
+def preprocess(x, scale=1.0, hflip=False, vflip=False, swap_rb=True, mean=None, std=None, divisor=32):
+    """Fused TTA pre-process + BGR swap + normalise + pad (one kernel, one HBM pass).
+    x: (N,3,H,W) float32 0..255 (contiguous NCHW) or (N,H,W,3) uint8 on the GPU.
+    Returns ((N,3,Hp,Wp) float32 tensor in channels_last storage, (Ho, Wo))."""
+    if x.dtype == torch.uint8:
+        assert x.dim() == 4 and x.shape[3] == 3, 'uint8 input must be (N,H,W,3)'
+        layout, (n, h, w) = 1, x.shape[:3]
+    else:
+        assert x.dim() == 4 and x.shape[1] == 3, 'float input must be (N,3,H,W)'
+        x = x.float()
+        layout, (n, h, w) = 0, (x.shape[0], x.shape[2], x.shape[3])
+    x = x.contiguous()
+    ho, wo, hp, wp = preprocess_out_shape(h, w, scale, divisor)
+    out = torch.empty((n, 3, hp, wp), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean]) if mean is not None else None
+    s3 = (C.c_float * 3)(*[float(v) for v in std]) if std is not None else None
+    _lib.check(_lib.lib().wd_preprocess_f32(_p(x), C.c_int(layout), C.c_int(n), C.c_int(h), C.c_int(w), C.c_double(scale),
+                                            C.c_int(1 if hflip else 0), C.c_int(1 if vflip else 0), C.c_int(1 if swap_rb else 0),
+                                            m3, s3, C.c_int(divisor), _p(out), _stream()), 'wd_preprocess_f32')
+    return out, (ho, wo)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # training (fwd + bwd): autograd wrappers around the forward kernels and the backward kernels of det_backward.hip
 def deform_im2col(x, offset, stride=1, pad=1):

@@ -155,8 +155,31 @@ class TTA(nn.Module):
             ttas.append(VFlipTTA())
         self.tta = SequentialTTA(ttas)
 
+    def _fused_pre(self):
+        """(scale, hflip, vflip) when the sequence is resize / flips only (the Waymo setting --tta x1.5,hflip) and the
+        detector can fold them into its pre-processing kernel; None otherwise."""
+        scale, hflip, vflip = 1.0, False, False
+        for t in self.tta:
+            if isinstance(t, OrigTTA):
+                continue
+            if isinstance(t, ResizeTTA) and not (hflip or vflip):     # resize must come before the flips to commute
+                scale *= float(t.scale_factor)
+            elif isinstance(t, HFlipTTA):
+                hflip = not hflip
+            elif isinstance(t, VFlipTTA):
+                vflip = not vflip
+            else:
+                return None
+        n_resize = sum(isinstance(t, ResizeTTA) for t in self.tta)
+        return (scale, hflip, vflip) if n_resize <= 1 else None
+
     def predict(self, x):
-        X = self.tta.pre_process([x])
-        Y = [self.detector.predict(xi) for xi in X]
+        fused = self._fused_pre() if hasattr(self.detector, 'predict_device') and torch.is_tensor(x) else None
+        if fused is not None:
+            # one HIP kernel: resize + flip + BGR + normalise + pad (tta.py:147-190 folded into the detector input)
+            Y = [self.detector.predict(x, *fused)]
+        else:
+            X = self.tta.pre_process([x])
+            Y = [self.detector.predict(xi) for xi in X]
         y = self.tta.post_process(Y)
         return y[0]

@@ -102,6 +102,17 @@ class Sort(object):
                                              C.byref(h)), 'wt_sort_create')
         self._h = h
         self._n_tracks = 0
+        self._borrowed = False
+
+    @classmethod
+    def _borrow(cls, handle, max_age, min_hits):
+        """View of a Sort owned by a wt_mct (MultiClassTrackerSort): same methods, never destroys the handle."""
+        self = cls.__new__(cls)
+        self.max_age, self.min_hits, self.frame_count, self.confidence_factor = max_age, min_hits, 0, 0.1
+        self._h = C.c_void_p(handle)
+        self._n_tracks = 0
+        self._borrowed = True
+        return self
 
     def update(self, dets, iou_threshold):
         """sort.py:244-296: dets (N,5) [x1,y1,x2,y2,score] (or empty) -> (K,6) [x1,y1,x2,y2,id+1,confidence]."""
@@ -130,7 +141,7 @@ class Sort(object):
 
     def __del__(self):
         h = getattr(self, '_h', None)
-        if h:
+        if h and not getattr(self, '_borrowed', False):
             try:
                 _lib.lib().wt_sort_destroy(h)
             except Exception:
