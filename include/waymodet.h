@@ -98,6 +98,13 @@ int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, 
 int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int stride,
                          int pad, float* dx, float* doffset, void* stream);
 
+/* 3x3 convolution (pad 1) with few output channels as "library GEMM + shift-add" (the 18-channel offset conv in front of
+ * every DeformConv, job.log:412): partial (N,H,W,ld) holds, per INPUT pixel, partial[tap*n_out + n] = sum_c x[c]*w[n][c][tap]
+ * (one GEMM against the (9*n_out, C) re-ordered weight, ld >= 9*n_out); this op writes
+ *   out (N,Ho,Wo,n_out)[y][x][n] = bias[n] + sum_{kh,kw} partial[y*stride+kh-1][x*stride+kw-1][(kh*3+kw)*n_out + n]. */
+int wd_tap_shift_add_f32(const float* partial, int ld, int n_out, const float* bias, int batch, int h, int w, int stride,
+                         float* out, void* stream);
+
 /* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
 int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
 

@@ -262,3 +262,17 @@ def test_preprocess_rejects_bad_arguments():
         ops.preprocess(x, 0.0)
     with pytest.raises(RuntimeError):
         ops.preprocess(x, 1.0, divisor=6)
+
+
+@pytest.mark.parametrize('C,H,W,stride', [(64, 13, 17, 1), (512, 40, 60, 1), (128, 16, 20, 2), (32, 1, 1, 1), (32, 5, 1, 1)])
+def test_conv3x3_few_vs_conv2d(C, H, W, stride):
+    """18-channel offset conv as GEMM + tap shift-add (wd_tap_shift_add_f32) == F.conv2d in float64, 1e-4 relative."""
+    g = torch.Generator().manual_seed(C + H)
+    x = _cl(torch.randn(2, C, H, W, generator=g))
+    w = torch.randn(18, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(18, generator=g)
+    got = ops.conv3x3_few(x, ops.tap_gemm_weight(w.cuda()), b.cuda(), 18, stride)
+    want = torch.nn.functional.conv2d(x.cpu().double(), w.double(), b.double(), stride, 1)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.cpu().double() - want).abs().max().item() / max(1.0, want.abs().max().item())
+    assert err < 1e-4, err

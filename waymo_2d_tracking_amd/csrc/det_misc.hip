@@ -56,6 +56,38 @@ __global__ __launch_bounds__(256) void groupnorm_relu_kernel(float* __restrict__
     }
 }
 
+// 3x3 convolution with FEW output channels (the 18-channel offset conv of every deformable block, job.log:412) as
+// "GEMM then shift-add": a library GEMM computes partial[p][tap*n_out + n] = sum_c x[p][c] * w[n][c][tap] for every
+// INPUT pixel p (N = 9*n_out = 162 fills the MFMA tiles, where a direct implicit GEMM pads 18 -> 32), and this kernel
+// gathers out[y][x][n] = bias[n] + sum_tap partial[(y*s + kh - 1, x*s + kw - 1)][tap*n_out + n] (zero padding).
+// One thread per output element; the 9 reads of a wave are 9 x (64 / n_out) contiguous n_out-float runs.
+__global__ __launch_bounds__(256) void tap_shift_add_kernel(const float* __restrict__ partial, int ld, int n_out,
+                                                            const float* __restrict__ bias, int batch, int H, int W,
+                                                            int Ho, int Wo, int stride, float* __restrict__ out) {
+    const long total = (long)batch * Ho * Wo * n_out;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i % n_out);
+        long p = i / n_out;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho), b = (int)(p / Ho);
+        float acc = bias ? bias[n] : 0.f;
+        const float* base = partial + (size_t)b * H * W * ld + n;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int y = oy * stride + kh - 1;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int x = ox * stride + kw - 1;
+                if (x < 0 || x >= W) continue;
+                acc += base[((size_t)y * W + x) * ld + (kh * 3 + kw) * n_out];
+            }
+        }
+        out[i] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const float* beta, int n, int hw, int c, int groups,
@@ -89,6 +121,24 @@ extern "C" int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int 
     const long blocks = (n4 + 255) / 256;
     hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream,
                        (float4*)y, (const float4*)bias, n4, n / 4, relu);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+extern "C" int wd_tap_shift_add_f32(const float* partial, int ld, int n_out, const float* bias, int batch, int h, int w,
+                                    int stride, float* out, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (batch <= 0 || h <= 0 || w <= 0) return WT_OK;
+    if (!partial || !out || n_out <= 0 || ld < 9 * n_out || stride < 1) {
+        wt::set_error("wd_tap_shift_add_f32: invalid arguments (ld=%d n_out=%d stride=%d)", ld, n_out, stride);
+        return WT_ERR_INVALID;
+    }
+    const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
+    const long total = (long)batch * ho * wo * n_out;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(tap_shift_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, ld, n_out, bias,
+                       batch, h, w, ho, wo, stride, out);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

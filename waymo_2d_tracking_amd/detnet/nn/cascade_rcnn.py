@@ -73,7 +73,9 @@ class Conv1x1(nn.Module):
             else:
                 y = torch.addmm(self.bias, a, self.weight.t())
         else:
-            y = torch.addmm(r, a, self.weight.t())
+            # inference: the residual buffer is dead after this block (block input or a fresh shortcut output), so the
+            # GEMM accumulates into it in place (beta = 1, C == D) - no copy of the residual into a new output
+            y = r.addmm_(a, self.weight.t()) if r.is_contiguous() else torch.addmm(r, a, self.weight.t())
             y = ops.bias_relu_(y, self.bias, relu)
         return y.view(n, h, w, -1).permute(0, 3, 1, 2)
 
@@ -128,6 +130,13 @@ class Bottleneck(nn.Module):
             self._packed_v = v
         return self._packed
 
+    def offset_conv(self, x):
+        w = self.conv2_offset.weight
+        if getattr(self, '_off_w2', None) is None or self._off_w2.device != w.device or self._off_v != w._version:
+            self._off_w2 = ops.tap_gemm_weight(w)
+            self._off_v = w._version
+        return ops.conv3x3_few(x, self._off_w2, self.conv2_offset.bias, 18, 1)
+
     def forward(self, x):
         sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)
         out = self.conv1(x, relu=True)
@@ -136,7 +145,9 @@ class Bottleneck(nn.Module):
             out = ops.DeformConvFn.apply(out, offset, self.conv2_weight, GROUPS, self.stride, 1)
             out = F.relu(out * self.conv2_scale.view(1, -1, 1, 1) + self.conv2_bias.view(1, -1, 1, 1))
         elif self.deform:
-            offset = self.conv2_offset(out)
+            # stride 1: library GEMM over the input pixels (162 columns) + tap shift-add kernel instead of a direct
+            # 18-channel implicit GEMM (MIOpen pads N 18 -> 32 and adds the bias in a second pass)
+            offset = self.offset_conv(out) if self.stride == 1 else self.conv2_offset(out)
             out = ops.deform_conv3x3(out, offset, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
                                      self.conv2_bias, relu=True)
         else:

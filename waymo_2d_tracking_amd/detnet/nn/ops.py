@@ -168,6 +168,31 @@ def groupnorm_relu_(x, weight, bias, groups, eps=1e-5, relu=True):
     return x
 
 
+def tap_gemm_weight(weight, align=16):
+    """(n_out, C, 3, 3) conv weight -> (ld, C) GEMM operand with row tap*n_out + n (tap = kh*3 + kw), zero rows up to
+    ld = 9*n_out rounded up to `align` (keeps the rows of the GEMM result 16-byte aligned)."""
+    n_out, c = weight.shape[0], weight.shape[1]
+    ld = (9 * n_out + align - 1) // align * align
+    w2 = torch.zeros((ld, c), dtype=torch.float32, device=weight.device)
+    w2[:9 * n_out] = weight.detach().float().permute(2, 3, 0, 1).reshape(9 * n_out, c)
+    return w2
+
+
+def conv3x3_few(x, w2, bias, n_out, stride=1):
+    """3x3 conv, pad 1, with few output channels (the 18-channel deformable-offset conv) = one library GEMM over the
+    input pixels (N = 9*n_out columns, full MFMA tiles) + the wd_tap_shift_add_f32 gather.  x (N,C,H,W) channels_last;
+    returns (N,n_out,Ho,Wo) channels_last."""
+    x = _nhwc(x)
+    n, c, h, w = x.shape
+    a = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
+    partial = torch.mm(a, w2.t())
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty((n, n_out, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().wd_tap_shift_add_f32(_p(partial), C.c_int(w2.shape[0]), C.c_int(n_out), _p(bias), C.c_int(n), C.c_int(h),
+                                               C.c_int(w), C.c_int(stride), _p(out), _stream()), 'wd_tap_shift_add_f32')
+    return out
+
+
 def preprocess_out_shape(h, w, scale=1.0, divisor=32):
     """(Ho, Wo, Hp, Wp) of preprocess(): resized extent and the extent padded to a multiple of `divisor`."""
     o = [C.c_int(0) for _ in range(4)]
