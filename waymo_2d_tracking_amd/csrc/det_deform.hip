@@ -23,12 +23,12 @@ constexpr int CCH = 128;        // channels per workgroup
 constexpr int LDC = CCH + 2;    // LDS row stride of the im2col slab
 
 struct Sample {
-    int idx[4];     // input pixel index (n*H*W + h*W + w) of the 4 corners; corners outside the image point at
-    float wgt[4];   // pixel 0 with weight 0, so the gather issues all its loads unconditionally (no branches)
-};
+    unsigned idx[4];  // BYTE offset of the corner pixel's channel vector (pixel index * C * 4); corners outside the image
+    float wgt[4];   // point at pixel 0 with weight 0, so the gather issues all its loads unconditionally (no branches)
+};                  // 32-bit offsets keep the gather's address math to one v_add per load (saddr + voffset form)
 
 template <int CG, bool DEFORM>
-__global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
+__global__ __launch_bounds__(256, (CG <= 32 ? 3 : 2)) void deform_conv3x3_kernel(
     const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
     const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ bias, int relu,
     int batch, int H, int W, int C, int Cout, int Ho, int Wo, int stride, int pad, float* __restrict__ y) {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
         const long gp = pix[p];
         Sample s;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s.idx[q] = 0; s.wgt[q] = 0.f; }
+        for (int q = 0; q < 4; ++q) { s.idx[q] = 0u; s.wgt[q] = 0.f; }
         if (gp >= 0) {
             const int n = (int)(gp / ((long)Ho * Wo));
             const int rem = (int)(gp - (long)n * Ho * Wo);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
             const int kh = k / 3, kw = k - 3 * kh;
             if (!DEFORM) {                    // plain grouped 3x3 convolution: one integer tap, zero padding
                 const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
-                if (hi >= 0 && hi < H && wi >= 0 && wi < W) { s.idx[0] = n * H * W + hi * W + wi; s.wgt[0] = 1.f; }
+                if (hi >= 0 && hi < H && wi >= 0 && wi < W) { s.idx[0] = (unsigned)(n * H * W + hi * W + wi) * (unsigned)C * 4u; s.wgt[0] = 1.f; }
                 tab[e] = s;
                 continue;
             }
@@ -101,10 +101,10 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
                 const float uh = 1.f - lh, uw = 1.f - lw;
                 const float m = mask ? mask[(size_t)gp * 9 + k] : 1.f;
                 const int base = n * H * W;
-                if (hl >= 0 && wl >= 0) { s.idx[0] = base + hl * W + wl; s.wgt[0] = uh * uw * m; }
-                if (hl >= 0 && wh <= W - 1) { s.idx[1] = base + hl * W + wh; s.wgt[1] = uh * lw * m; }
-                if (hh <= H - 1 && wl >= 0) { s.idx[2] = base + hh * W + wl; s.wgt[2] = lh * uw * m; }
-                if (hh <= H - 1 && wh <= W - 1) { s.idx[3] = base + hh * W + wh; s.wgt[3] = lh * lw * m; }
+                if (hl >= 0 && wl >= 0) { s.idx[0] = (unsigned)(base + hl * W + wl) * (unsigned)C * 4u; s.wgt[0] = uh * uw * m; }
+                if (hl >= 0 && wh <= W - 1) { s.idx[1] = (unsigned)(base + hl * W + wh) * (unsigned)C * 4u; s.wgt[1] = uh * lw * m; }
+                if (hh <= H - 1 && wl >= 0) { s.idx[2] = (unsigned)(base + hh * W + wl) * (unsigned)C * 4u; s.wgt[2] = lh * uw * m; }
+                if (hh <= H - 1 && wh <= W - 1) { s.idx[3] = (unsigned)(base + hh * W + wh) * (unsigned)C * 4u; s.wgt[3] = lh * lw * m; }
             }
         }
         tab[e] = s;
@@ -123,81 +123,91 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_kernel(
     // slab barrier and stays in flight under the MFMAs of tap k (PMC on the unpipelined loop: 53 % of wave cycles in
     // s_waitcnt / barriers, 14 % issuing); only the second half's latency is exposed.
     constexpr int NQ = DEFORM ? 4 : 1;
+    const char* xb = reinterpret_cast<const char*>(x);
+    const unsigned lane_off = (unsigned)(c0 + gq * 4) * 4u;
     float4 tA[4][NQ];
-    float wA[4][NQ];
-    auto issue = [&](int k, int half, float4 (&t)[4][NQ], float (&wq)[4][NQ]) {
+    // the bilinear weights are re-read from the LDS table at blend time (broadcast reads) instead of living in 16
+    // VGPRs across the MFMA phase: that register room holds the prefetched B operands below at 3 waves / SIMD
+    auto issue = [&](int k, int half, float4 (&t)[4][NQ]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = gp0 + 8 * (half * 4 + i);
-            const Sample s = tab[p * 9 + k];
+            const Sample& s = tab[p * 9 + k];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                t[i][q] = *reinterpret_cast<const float4*>(x + (size_t)s.idx[q] * C + c0 + gq * 4);
-                wq[i][q] = s.wgt[q];
-            }
+            for (int q = 0; q < NQ; ++q)
+                t[i][q] = *reinterpret_cast<const float4*>(xb + (size_t)(s.idx[q] + lane_off));
         }
     };
-    auto blend = [&](int half, const float4 (&t)[4][NQ], const float (&wq)[4][NQ]) {
+    auto blend = [&](int k, int half, const float4 (&t)[4][NQ]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = gp0 + 8 * (half * 4 + i);
+            const Sample& s = tab[p * 9 + k];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                v.x += wq[i][q] * t[i][q].x; v.y += wq[i][q] * t[i][q].y;
-                v.z += wq[i][q] * t[i][q].z; v.w += wq[i][q] * t[i][q].w;
+                const float wq = s.wgt[q];
+                v.x += wq * t[i][q].x; v.y += wq * t[i][q].y;
+                v.z += wq * t[i][q].z; v.w += wq * t[i][q].w;
             }
             float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
         }
     };
-    issue(0, 0, tA, wA);
-    for (int k = 0; k < 9; ++k) {
-        // ---- 2. gather + blend the tap's im2col slab ----
-        blend(0, tA, wA);
-        {
-            float4 tB[4][NQ];
-            float wB[4][NQ];
-            issue(k, 1, tB, wB);
-            blend(1, tB, wB);
-        }
-        __syncthreads();
-        if (k + 1 < 9) issue(k + 1, 0, tA, wA);          // in flight during the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- 3. MFMA: out[64 px][32 co of this wave] += slab[64 px][ci of the group] * W[ci][co] ----
+    // B operands (this wave's weights of tap k) are fetched BEFORE the second half of the gather: vector loads return
+    // in order, so a B load queued behind the next tap's prefetch would make the MFMAs wait for that prefetch too.
+    constexpr int KS = (CG >= 16) ? CG / 4 : 4;          // k-steps per N tile
+    float bR[2][KS];
+    auto load_b = [&](int k) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int co_l = co_w + 16 * nt;                 // first co of this N tile inside the chunk
+            const int co_l = co_w + 16 * nt;
             if (CG >= 16) {
-                const int g_l = co_l / CG;                       // group inside the chunk
-                const int g = (c0 + co_l) / CG;                  // global group
-                const int co_g = (co_l % CG) + (lane & 15);      // co inside the group
+                const int g = (c0 + co_l) / CG;
+                const int co_g = (co_l % CG) + (lane & 15);
                 const float* wb = wp + ((size_t)(g * 9 + k) * CG) * CG + co_g;
 #pragma unroll
-                for (int kk = 0; kk < CG / 4; ++kk) {
-                    const int ci = kk * 4 + (lane >> 4);
-                    const float b = wb[(size_t)ci * CG];
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const float a = col[(mt * 16 + (lane & 15)) * LDC + g_l * CG + ci];
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt][nt], 0, 0, 0);
-                    }
-                }
+                for (int kk = 0; kk < KS; ++kk) bR[nt][kk] = wb[(size_t)(kk * 4 + (lane >> 4)) * CG];
             } else {
                 // CG == 8: the 16-wide N tile spans two groups -> block-diagonal B over the 16 input channels
                 const int j = lane & 15;
                 const int g = (c0 + co_l) / 8 + (j >> 3);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                for (int kk = 0; kk < KS; ++kk) {
                     const int ci = kk * 4 + (lane >> 4);         // 0..15 inside the tile's channel range
                     const float wv = wp[((size_t)(g * 9 + k) * 8 + (ci & 7)) * 8 + (j & 7)];
-                    const float b = ((ci >> 3) == (j >> 3)) ? wv : 0.f;
+                    bR[nt][kk] = ((ci >> 3) == (j >> 3)) ? wv : 0.f;
+                }
+            }
+        }
+    };
+    issue(0, 0, tA);
+    for (int k = 0; k < 9; ++k) {
+        // ---- 2. gather + blend the tap's im2col slab ----
+        blend(k, 0, tA);
+        load_b(k);
+        {
+            float4 tB[4][NQ];
+            issue(k, 1, tB);
+            __builtin_amdgcn_sched_barrier(0);           // keep all 16 loads in flight (the scheduler would serialise
+            blend(k, 1, tB);                             // them 4 at a time to save registers)
+        }
+        __syncthreads();
+        if (k + 1 < 9) issue(k + 1, 0, tA);              // in flight during the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 3. MFMA: out[64 px][32 co of this wave] += slab[64 px][ci of the group] * W[ci][co] ----
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const float a = col[(mt * 16 + (lane & 15)) * LDC + co_l + ci];
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt][nt], 0, 0, 0);
-                    }
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co_l = co_w + 16 * nt;                 // first co of this N tile inside the chunk
+            const int a_col = (CG >= 16) ? (co_l / CG) * CG : co_l;   // first slab column of the tile's input channels
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int ci = kk * 4 + (lane >> 4);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float a = col[(mt * 16 + (lane & 15)) * LDC + a_col + ci];
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bR[nt][kk], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
@@ -427,6 +437,11 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
         wt::set_error("wd_deform_conv3x3_f32: unsupported shape (c_in=%d c_out=%d groups=%d; need c_in == c_out, c_in %% 128 == 0)",
                       c_in, c_out, groups);
         return WT_ERR_INVALID;
+    }
+    if ((double)batch * h * w * c_in * 4.0 >= 4294967296.0) {
+        wt::set_error("wd_deform_conv3x3_f32: input of %d x %d x %d x %d floats exceeds the kernel's 32-bit byte offsets (4 GiB); "
+                      "split the batch", batch, h, w, c_in);
+        return WT_ERR_CAPACITY;
     }
     const int cg = c_in / groups;
     const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
