@@ -32,8 +32,14 @@ __global__ __launch_bounds__(256, (CG <= 32 ? 3 : 2)) void deform_conv3x3_kernel
     const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
     const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ bias, int relu,
     int batch, int H, int W, int C, int Cout, int Ho, int Wo, int stride, int pad, float* __restrict__ y) {
+    // CG <= 32: every wave gathers, stages and multiplies ITS OWN 32 channels (wave-private 64 x 32 slab, row stride
+    // 34): producer and consumer of a slab are the same wave, so the tap loop needs no workgroup barrier at all and
+    // the 12 waves of a CU drift apart - one wave's MFMAs run under another wave's gather latency.
+    // CG == 64: a group spans two waves; the shared 64 x 128 slab with two barriers per tap is kept.
+    constexpr bool PRIV = CG <= 32;
+    constexpr int LDW = PRIV ? 34 : LDC;
     __shared__ Sample tab[TP * 9];
-    __shared__ __attribute__((aligned(16))) float col[TP * LDC];
+    __shared__ __attribute__((aligned(16))) float col[PRIV ? 4 * TP * 34 : TP * LDC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware work mapping (speed only): workgroup b is dispatched to XCD b % 8, whose private 4 MiB L2 should see
     // a compact slice of the input.  The gather re-reads every input pixel ~9x per channel chunk, so each XCD gets
@@ -116,15 +122,25 @@ __global__ __launch_bounds__(256, (CG <= 32 ? 3 : 2)) void deform_conv3x3_kernel
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    const int gq = tid & 31;           // float4 column of the slab this thread gathers
-    const int gp0 = tid >> 5;          // first pixel row (rows gp0, gp0 + 8, ...)
+    const int gq = PRIV ? (lane & 7) : (tid & 31);     // float4 column of the slab this thread gathers
+    const int gp0 = PRIV ? (lane >> 3) : (tid >> 5);   // first pixel row (rows gp0, gp0 + 8, ...)
     const int co_w = wave * 32;        // this wave's 32 output channels inside the chunk
+    float* colw = PRIV ? col + wave * (TP * 34) : col;
+    auto slab_sync = [&]() {
+        if (PRIV) {                    // same-wave LDS traffic is executed in order: only the compiler must not reorder
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
     // Software pipeline: the first half of tap k+1's gather (16 x 16-byte loads per lane) is issued right after the
     // slab barrier and stays in flight under the MFMAs of tap k (PMC on the unpipelined loop: 53 % of wave cycles in
     // s_waitcnt / barriers, 14 % issuing); only the second half's latency is exposed.
     constexpr int NQ = DEFORM ? 4 : 1;
     const char* xb = reinterpret_cast<const char*>(x);
-    const unsigned lane_off = (unsigned)(c0 + gq * 4) * 4u;
+    const unsigned lane_off = (unsigned)(c0 + (PRIV ? co_w : 0) + gq * 4) * 4u;
     float4 tA[4][NQ];
     // the bilinear weights are re-read from the LDS table at blend time (broadcast reads) instead of living in 16
     // VGPRs across the MFMA phase: that register room holds the prefetched B operands below at 3 waves / SIMD
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(256, (CG <= 32 ? 3 : 2)) void deform_conv3x3_kernel
                 v.x += wq * t[i][q].x; v.y += wq * t[i][q].y;
                 v.z += wq * t[i][q].z; v.w += wq * t[i][q].w;
             }
-            float2* d = reinterpret_cast<float2*>(&col[p * LDC + gq * 4]);
+            float2* d = reinterpret_cast<float2*>(&colw[p * LDW + gq * 4]);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
         }
@@ -193,25 +209,27 @@ __global__ __launch_bounds__(256, (CG <= 32 ? 3 : 2)) void deform_conv3x3_kernel
             __builtin_amdgcn_sched_barrier(0);           // keep all 16 loads in flight (the scheduler would serialise
             blend(k, 1, tB);                             // them 4 at a time to save registers)
         }
-        __syncthreads();
+        slab_sync();
         if (k + 1 < 9) issue(k + 1, 0, tA);              // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);
         // ---- 3. MFMA: out[64 px][32 co of this wave] += slab[64 px][ci of the group] * W[ci][co] ----
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int co_l = co_w + 16 * nt;                 // first co of this N tile inside the chunk
-            const int a_col = (CG >= 16) ? (co_l / CG) * CG : co_l;   // first slab column of the tile's input channels
+            // first slab column of the tile's input channels (wave-private slabs hold only the wave's 32 channels)
+            const int cl = PRIV ? 16 * nt : co_l;
+            const int a_col = (CG >= 16) ? (cl / CG) * CG : cl;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 const int ci = kk * 4 + (lane >> 4);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const float a = col[(mt * 16 + (lane & 15)) * LDC + a_col + ci];
+                    const float a = colw[(mt * 16 + (lane & 15)) * LDW + a_col + ci];
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bR[nt][kk], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
-        __syncthreads();
+        slab_sync();
     }
     // ---- 4. epilogue ----
 #pragma unroll
