@@ -51,6 +51,8 @@ int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_
  *   y      : (N, H_out, W_out, C_out) NHWC float32,  H_out = (H + 2*pad - 3)/stride + 1 */
 size_t wd_deform_packed_weight_floats(int c_in, int c_out, int groups);
 int wd_deform_pack_weight(const float* weight_oihw, int c_in, int c_out, int groups, float* packed, void* stream);
+/* Name of the kernel wd_deform_conv3x3_f32 dispatches for a shape (host-only; profiling / bench labels). */
+const char* wd_deform_conv3x3_variant(int c_in, int groups, int stride, int pad, int has_offset);
 int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
                           const float* scale, const float* bias, int relu,
                           int batch, int h, int w, int c_in, int c_out, int groups, int stride, int pad,

@@ -276,3 +276,26 @@ def test_conv3x3_few_vs_conv2d(C, H, W, stride):
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     err = (got.cpu().double() - want).abs().max().item() / max(1.0, want.abs().max().item())
     assert err < 1e-4, err
+
+
+@pytest.mark.parametrize('variant', ['lds', 'none', 'all'])
+@pytest.mark.parametrize('C,off_std', [(512, 0.6), (1024, 0.6), (1024, 3.0)])
+def test_deform_conv_every_kernel_variant(monkeypatch, variant, C, off_std):
+    """The three stride-1 kernels behind wd_deform_conv3x3_f32 (LDS patch + register fragments [default], L1 gather,
+    LDS patch + shared slab) against the float64 restatement: small offsets (all samples inside the patch: the pipelined
+    fast path) and large ones (per-sample global fallback), modulated, tile edges that are not multiples of 8."""
+    from oracle import detops_ref as R
+    monkeypatch.setenv('WD_DEFORM_PATCH', variant)
+    name = ops._lib.lib().wd_deform_conv3x3_variant
+    name.restype = __import__('ctypes').c_char_p
+    expect = {'lds': b'lds_kernel', 'none': b'deform_conv3x3_kernel', 'all': b'patch_kernel'}[variant]
+    assert expect in name(C, 32, 1, 1, 1)
+    g = torch.Generator().manual_seed(C + int(off_std * 10))
+    H, W = 19, 27
+    x = torch.randn((1, C, H, W), generator=g)
+    offset = torch.randn((1, 18, H, W), generator=g) * off_std
+    weight = torch.randn((C, C // 32, 3, 3), generator=g) / (3 * (C // 32) ** 0.5)
+    mask = torch.rand((1, 9, H, W), generator=g)
+    exp = R.deform_conv3x3(x, offset, weight, 32, 1, 1, mask)
+    got = ops.deform_conv3x3(_cl(x), _cl(offset), ops.deform_pack_weight(weight.cuda(), 32), 32, 1, 1, mask=_cl(mask))
+    np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)

@@ -119,7 +119,7 @@ def run(args, world, rank, timed_steps):
         tag = max(deform, key=lambda k: deform[k][1])
         cnt, ms, flops = deform[tag]
         ach = flops / (ms / cnt * 1e-3) / 1e12
-        roofline = dict(bound='mfma', kernel='deform_conv3x3_kernel<32,true> [%s]' % tag, achieved=ach, peak=157.3,
+        roofline = dict(bound='mfma', kernel=tag, achieved=ach, peak=157.3,
                         unit='TFLOP/s', frac=ach / 157.3, traffic=None, launches=cnt, avg_us=ms / cnt * 1e3,
                         flops_per_launch=flops,
                         all_shapes={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, tflops=v[2] / (v[1] / v[0] * 1e-3) / 1e12)

@@ -19,6 +19,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-Wall', '-Wno-unused-function']
+COMMON += os.environ.get('WD_HIPCC_FLAGS', '').split()          # experiments (e.g. -DWD_DBG=1)
 # unit -> extra flags
 UNITS = {
     'api.hip': [],

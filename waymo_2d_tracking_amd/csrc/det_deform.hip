@@ -413,6 +413,304 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_patch_kernel(
         }
 }
 
+// ---- stride-1, 16 / 32 channels per group: LDS patch + sampling table + WAVE-PRIVATE slabs -------------------------
+// PMC on the L1-gather kernel (tools/pmc_deform.sh, res4): texture path (TA 50 % / TD 66 % busy) and MFMA (37 %) take
+// turns - every bilinear corner (64 px x 9 taps x 4) travels through the vector-memory return path although a tile only
+// touches ~14 x 14 distinct input pixels.  Here each of those pixels crosses that path ONCE per 64-channel chunk
+// (patch in LDS, zero-filled outside the image) and the 2304 corner reads are ds_read_b128 (4x the L1 width).
+//   * sampling table (built once per workgroup): patch offset of corner (hl, wl) + the 4 bilinear weights (x mask);
+//     samples whose corners leave the patch (|offset| > ~2 px) are flagged and read from global memory;
+//   * a wave owns (group, pixel range): it blends ITS channels of ITS pixels into a private slab and multiplies them,
+//     so the tap loop has no workgroup barrier; B operands of tap k+1 are requested before the MFMAs of tap k.
+#ifndef WD_DBG
+#define WD_DBG 0
+#endif
+constexpr int PST = PCH + 4;         // patch pixel stride in floats: 16 lanes reading 16 different pixels at the same
+                                     // channel offset hit 16 different 4-bank groups (conflict-free ds_read_b128)
+template <int CG>
+__global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
+    const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
+    const float* __restrict__ wp, const float* __restrict__ scale, const float* __restrict__ bias, int relu,
+    int batch, int H, int W, int C, int Cout, int Ho, int Wo, float* __restrict__ y) {
+    constexpr int GPW = PCH / CG;            // groups per workgroup (2 / 4)
+    constexpr int WPG = 4 / GPW;             // waves per group (2 / 1)
+    constexpr int MT = 4 / WPG;              // 16-pixel M tiles per wave (2 / 4)
+    constexpr int NT = CG / 16;              // 16-channel N tiles per wave (2 / 1)
+    constexpr int KS = CG / 4;               // k-steps per tap (8 / 4) = channels blended per lane
+    constexpr int PW = 16 * MT;              // pixels per wave (32 / 64)
+    __shared__ __attribute__((aligned(16))) float patch[PS * PS * PST];
+    __shared__ __attribute__((aligned(16))) float4 tw[TP * 9];
+    __shared__ int toff[TP * 9];
+    __shared__ int pix[TP];
+    __shared__ int any_fb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
+    const int ntiles = batch * tiles_y * tiles_x;
+    const int nchunks = C / PCH;
+    int tile, chunk;
+    {
+        const int b = blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        if ((nchunks & 7) == 0) {                    // whole channel chunks per XCD (see the L1-gather kernel)
+            const int cpx = nchunks >> 3;
+            chunk = xcd * cpx + slot % cpx;
+            tile = slot / cpx;
+        } else {
+            chunk = b / ntiles;
+            tile = b - chunk * ntiles;
+        }
+    }
+    if (tile >= ntiles || chunk >= nchunks) return;
+    const int tn = tile / (tiles_y * tiles_x);
+    const int trem = tile - tn * tiles_y * tiles_x;
+    const int tyy = trem / tiles_x, txx = trem - tyy * tiles_x;
+    const int c0 = chunk * PCH;
+    const int py0 = tyy * 8 - 1 - PR, px0 = txx * 8 - 1 - PR;       // image coordinates of patch pixel (0, 0)
+    if (tid == 0) any_fb = 0;
+    if (tid < TP) {
+        const int ho = tyy * 8 + (tid >> 3), wo = txx * 8 + (tid & 7);
+        pix[tid] = (ho < Ho && wo < Wo) ? (tn * Ho + ho) * Wo + wo : -1;
+    }
+    // MFMA A fragments are blended straight into registers: lane (row r = lane & 15, kq = lane >> 4) owns pixel r of each
+    // M tile and the KS consecutive channels [kq * KS, kq * KS + KS) of its group; k-step kk then multiplies channel
+    // kq * KS + kk (a permutation of the reduction index, applied identically to the B operand below).
+    const int g_l = wave / WPG;                          // group inside the chunk
+    const int p_base = (wave % WPG) * PW;                // first pixel of this wave
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int ch_l = g_l * CG + kq * KS;                 // first channel (inside the chunk) this lane blends
+    const int g = (c0 + g_l * CG) / CG;                  // global group
+    float bR[2][NT][KS];
+    auto load_b = [&](int k, float (&b)[NT][KS]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float* wb = wp + ((size_t)(g * 9 + k) * CG) * CG + 16 * nt + r16;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) b[nt][kk] = wb[(size_t)(kq * KS + kk) * CG];
+        }
+    };
+    load_b(0, bR[0]);              // tap 0's weights: their L2 latency hides behind the patch fill and the table build
+    // ---- table inputs (offsets / mask of up to 3 (pixel, tap) entries per thread) are requested before the patch
+    //      loads, so the prologue pays ONE global round trip ----
+    constexpr int NE = (TP * 9 + 255) / 256;
+    float e_dy[NE], e_dx[NE], e_m[NE];
+    int e_gp[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + 256 * j;
+        const int p = e / 9, k = e - 9 * p;
+        int gp = -1;
+        if (e < TP * 9) {
+            const int ho = tyy * 8 + (p >> 3), wo = txx * 8 + (p & 7);
+            gp = (ho < Ho && wo < Wo) ? (tn * Ho + ho) * Wo + wo : -1;
+        }
+        e_gp[j] = gp;
+        e_dy[j] = e_dx[j] = 0.f;
+        e_m[j] = 1.f;
+        if (gp >= 0 && WD_DBG != 4) {
+            e_dy[j] = offset[(size_t)gp * 18 + 2 * k];
+            e_dx[j] = offset[(size_t)gp * 18 + 2 * k + 1];
+            if (mask) e_m[j] = mask[(size_t)gp * 9 + k];
+        }
+    }
+    // ---- stage the patch (zero outside the image): all loads of a thread in flight, then the LDS stores ----
+    {
+        constexpr int NL = (PS * PS * (PCH / 4) + 255) / 256;
+        float4 v[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + 256 * j;
+            const int pp = e >> 4, q = e & 15;
+            const int r = pp / PS, cc = pp - r * PS;
+            const int iy = py0 + r, ix = px0 + cc;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (WD_DBG != 3 && e < PS * PS * (PCH / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v[j] = *reinterpret_cast<const float4*>(x + ((size_t)(tn * H + iy) * W + ix) * C + c0 + q * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + 256 * j;
+            if (e < PS * PS * (PCH / 4)) *reinterpret_cast<float4*>(&patch[(e >> 4) * PST + (e & 15) * 4]) = v[j];
+        }
+    }
+    __syncthreads();                                  // any_fb = 0 above is ordered before the table's any_fb = 1
+    // ---- sampling table ----
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = tid + 256 * j;
+        if (e >= TP * 9) continue;
+        const int p = e / 9, k = e - 9 * p;
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int off = 0;
+        if (e_gp[j] >= 0) {
+            const int kh = k / 3, kw = k - 3 * kh;
+            const float ry = (float)((p >> 3) + kh + PR) + e_dy[j];        // patch coordinates
+            const float rx = (float)((p & 7) + kw + PR) + e_dx[j];
+            const float h_im = ry + (float)py0, w_im = rx + (float)px0;
+            const float m = e_m[j];
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+                const float fy = floorf(ry), fx = floorf(rx);
+                const int hl = (int)fy, wl = (int)fx;
+                const float lh = ry - fy, lw = rx - fx, uh = 1.f - lh, uw = 1.f - lw;
+                w4 = make_float4(uh * uw * m, uh * lw * m, lh * uw * m, lh * lw * m);
+                if (hl >= 0 && hl < PS - 1 && wl >= 0 && wl < PS - 1) {
+                    off = (hl * PS + wl) * PST;
+                } else {                          // corners outside the patch: image coordinates packed for the slow path
+                    off = -1 - ((hl + py0 + 2) * (W + 4) + (wl + px0 + 2));
+                    any_fb = 1;
+                }
+            }
+        }
+        tw[e] = w4;
+        toff[e] = off;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const bool slow = any_fb != 0;
+
+    auto mfma = [&](const float (&a)[MT][KS], const float (&b)[NT][KS]) {
+#pragma unroll
+        for (int kk = 0; kk < (WD_DBG == 1 ? 1 : KS); ++kk)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kk], b[nt][kk], acc[mt][nt], 0, 0, 0);
+    };
+    if (WD_DBG == 8) {
+    } else if (!slow) {
+        // Software pipeline inside the wave: the LDS reads of tap k+1 are issued BEFORE the MFMA burst of tap k and blended
+        // after it has been issued, so corner latency and blend VALU run under the matrix pipe's 32-cycle instructions.
+        // (Waves of a SIMD issue their MFMAs round-robin and stay in phase: without this, every wave gathers while the
+        // matrix pipe idles and vice versa - measured: t(gather only) + t(MFMA only) == t(kernel).)
+        float4 cv[MT][4][KS / 4];
+        float4 wv[MT];
+        float a[2][MT][KS];
+        auto gather_issue = [&](int k) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int e = (p_base + mt * 16 + r16) * 9 + k;
+                const float* pb = &patch[toff[e] + ch_l];
+                wv[mt] = tw[e];
+#pragma unroll
+                for (int h = 0; h < KS / 4; ++h) {
+                    cv[mt][0][h] = *reinterpret_cast<const float4*>(pb + 4 * h);
+                    cv[mt][1][h] = *reinterpret_cast<const float4*>(pb + PST + 4 * h);
+                    cv[mt][2][h] = *reinterpret_cast<const float4*>(pb + PS * PST + 4 * h);
+                    cv[mt][3][h] = *reinterpret_cast<const float4*>(pb + PS * PST + PST + 4 * h);
+                }
+            }
+        };
+        auto blend = [&](float (&o)[MT][KS]) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int h = 0; h < KS / 4; ++h) {
+                    o[mt][4 * h + 0] = wv[mt].x * cv[mt][0][h].x + wv[mt].y * cv[mt][1][h].x + wv[mt].z * cv[mt][2][h].x + wv[mt].w * cv[mt][3][h].x;
+                    o[mt][4 * h + 1] = wv[mt].x * cv[mt][0][h].y + wv[mt].y * cv[mt][1][h].y + wv[mt].z * cv[mt][2][h].y + wv[mt].w * cv[mt][3][h].y;
+                    o[mt][4 * h + 2] = wv[mt].x * cv[mt][0][h].z + wv[mt].y * cv[mt][1][h].z + wv[mt].z * cv[mt][2][h].z + wv[mt].w * cv[mt][3][h].z;
+                    o[mt][4 * h + 3] = wv[mt].x * cv[mt][0][h].w + wv[mt].y * cv[mt][1][h].w + wv[mt].z * cv[mt][2][h].w + wv[mt].w * cv[mt][3][h].w;
+                }
+        };
+        if (WD_DBG != 2) { gather_issue(0); blend(a[0]); }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k + 1 < 9) load_b(k + 1, bR[(k + 1) & 1]);
+            if (k + 1 < 9 && WD_DBG != 2) gather_issue(k + 1);
+            if (WD_DBG == 7) __builtin_amdgcn_sched_barrier(0);
+            mfma(a[k & 1], bR[k & 1]);
+            if (WD_DBG == 7) __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < 9 && WD_DBG != 2) blend(a[(k + 1) & 1]);
+            if (WD_DBG != 5 && WD_DBG != 7 && k + 1 < 9) {
+                // interleave inside the MFMA burst (a wave issues in order: VALU / LDS instructions only overlap the matrix
+                // pipe when they sit BETWEEN two MFMAs): first the LDS reads of tap k+1, then its blend VALU
+                constexpr int NM = MT * NT * KS;            // MFMAs per tap (32 / 16)
+                constexpr int NDS = MT * (2 + KS);          // LDS reads per tap
+                constexpr int H1 = NM / 4;
+                __builtin_amdgcn_sched_group_barrier(0x020, NT * KS, 0);      // B operands of tap k+1 first (oldest in vmcnt order)
+#pragma unroll
+                for (int j = 0; j < H1; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, (NDS + H1 - 1) / H1, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < NM / 4; ++j) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                for (int j = 0; j < NM - H1 - NM / 4; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (MT * KS * 4 + (NM - H1 - NM / 4) - 1) / (NM - H1 - NM / 4), 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // large offsets somewhere in the tile: per-sample choice between the patch and global memory (not pipelined)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k + 1 < 9) load_b(k + 1, bR[(k + 1) & 1]);
+            float a[MT][KS];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int e = (p_base + mt * 16 + r16) * 9 + k;
+                const int off = toff[e];
+                const float4 w4 = tw[e];
+                const float wq[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) a[mt][kk] = 0.f;
+                if (off >= 0) {
+                    const float* pb = &patch[off + ch_l];
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                        for (int h = 0; h < KS / 4; ++h) {
+                            const float4 t = *reinterpret_cast<const float4*>(pb + (qd >> 1) * PS * PST + (qd & 1) * PST + 4 * h);
+                            a[mt][4 * h + 0] += wq[qd] * t.x; a[mt][4 * h + 1] += wq[qd] * t.y;
+                            a[mt][4 * h + 2] += wq[qd] * t.z; a[mt][4 * h + 3] += wq[qd] * t.w;
+                        }
+                } else {
+                    const int code = -1 - off;
+                    const int ih = code / (W + 4) - 2, iw = code - (ih + 2) * (W + 4) - 2;
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int yy = ih + (qd >> 1), xx = iw + (qd & 1);
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                            const float* gb = x + ((size_t)(tn * H + yy) * W + xx) * C + c0 + ch_l;
+#pragma unroll
+                            for (int h = 0; h < KS / 4; ++h) {
+                                const float4 t = *reinterpret_cast<const float4*>(gb + 4 * h);
+                                a[mt][4 * h + 0] += wq[qd] * t.x; a[mt][4 * h + 1] += wq[qd] * t.y;
+                                a[mt][4 * h + 2] += wq[qd] * t.z; a[mt][4 * h + 3] += wq[qd] * t.w;
+                            }
+                        }
+                    }
+                }
+            }
+            mfma(a, bR[k & 1]);
+        }
+    }
+    // ---- epilogue ----
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = c0 + g_l * CG + 16 * nt + (lane & 15);
+        const float sc = scale ? scale[co] : 1.f;
+        const float bi = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long gp = pix[p_base + mt * 16 + (lane >> 4) * 4 + r];
+                if (gp >= 0) {
+                    float v = acc[mt][nt][r] * sc + bi;
+                    if (relu) v = fmaxf(v, 0.f);
+                    y[(size_t)gp * Cout + co] = v;
+                }
+            }
+    }
+}
+
 // (C_out, C_in/groups, 3, 3) OIHW -> [group][tap][ci][co]
 __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout, float* __restrict__ packed) {
     const long total = (long)cout * cg * 9;
@@ -428,7 +726,29 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout
 
 }  // namespace
 
+// 0 = L1-gather kernel, 1 = LDS patch + shared slab, 2 = LDS patch + register A fragments
+static int deform_variant(int cg, int stride, int pad, bool has_offset, const char* mode) {
+    const bool fits = has_offset && stride == 1 && pad == 1;
+    if (mode && strcmp(mode, "none") == 0) return 0;
+    if (mode && strcmp(mode, "all") == 0) return (fits && (cg == 16 || cg == 32 || cg == 64)) ? 1 : 0;
+    if (fits && (cg == 16 || cg == 32)) return 2;
+    if (fits && cg == 64) return 1;
+    return 0;
+}
+
 extern "C" {
+
+const char* wd_deform_conv3x3_variant(int c_in, int groups, int stride, int pad, int has_offset) {
+    if (groups <= 0 || c_in % groups) return "invalid";
+    const int cg = c_in / groups;
+    switch (deform_variant(cg, stride, pad, has_offset != 0, getenv("WD_DEFORM_PATCH"))) {
+        case 2: return cg == 16 ? "deform_conv3x3_lds_kernel<16>" : "deform_conv3x3_lds_kernel<32>";
+        case 1: return cg == 16 ? "deform_conv3x3_patch_kernel<16>" : cg == 32 ? "deform_conv3x3_patch_kernel<32>" : "deform_conv3x3_patch_kernel<64>";
+        default: break;
+    }
+    if (has_offset) return cg == 8 ? "deform_conv3x3_kernel<8,true>" : cg == 16 ? "deform_conv3x3_kernel<16,true>" : cg == 32 ? "deform_conv3x3_kernel<32,true>" : "deform_conv3x3_kernel<64,true>";
+    return cg == 8 ? "deform_conv3x3_kernel<8,false>" : cg == 16 ? "deform_conv3x3_kernel<16,false>" : cg == 32 ? "deform_conv3x3_kernel<32,false>" : "deform_conv3x3_kernel<64,false>";
+}
 
 size_t wd_deform_packed_weight_floats(int c_in, int c_out, int groups) {
     if (groups <= 0 || c_in % groups || c_in != c_out) return 0;
@@ -472,9 +792,24 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
     // measured on MI355X (tools/deform_bench.py): the LDS-patch kernel wins for 64 channels per group (res5: 96 vs
     // 110 us) and loses to the L1-gather kernel for 16 / 32 (res3 / res4), where its smaller 64-channel chunks
     // expose the per-tap barrier latency; WD_DEFORM_PATCH=all|none overrides for experiments
+    // dispatch measured on MI355X (tools/deform_bench.py, bench.py): stride 1 with offsets -> LDS-patch kernels
+    // (16 / 32 channels per group: register-fragment kernel, 64: shared-slab patch kernel); stride 2, plain grouped
+    // convolution and 8 channels per group -> L1-gather kernel.  WD_DEFORM_PATCH=lds|all|none overrides (experiments).
     const char* mode = getenv("WD_DEFORM_PATCH");
-    const bool want_patch = mode ? (strcmp(mode, "all") == 0) : (cg == 64);
-    if (offset && stride == 1 && pad == 1 && (cg == 16 || cg == 32 || cg == 64) && want_patch) {
+    const int variant = deform_variant(cg, stride, pad, offset != nullptr, mode);
+    if (variant == 2) {
+        const long nwg_p = ntiles * (c_in / PCH);
+        dim3 gridp((unsigned)((nwg_p + 7) / 8 * 8));
+        if (cg == 16)
+            hipLaunchKernelGGL(deform_conv3x3_lds_kernel<16>, gridp, dim3(256), 0, stream, x, offset, mask, packed_weight, scale,
+                               bias, relu, batch, h, w, c_in, c_out, ho, wo, y);
+        else
+            hipLaunchKernelGGL(deform_conv3x3_lds_kernel<32>, gridp, dim3(256), 0, stream, x, offset, mask, packed_weight, scale,
+                               bias, relu, batch, h, w, c_in, c_out, ho, wo, y);
+        WT_HIP(hipGetLastError());
+        return WT_OK;
+    }
+    if (variant == 1) {
         const long nwg_p = ntiles * (c_in / PCH);
         dim3 gridp((unsigned)((nwg_p + 7) / 8 * 8));
 #define WD_LAUNCH_P(CG)                                                                                              \

@@ -129,7 +129,10 @@ def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None
                'wd_deform_conv3x3_f32')
     if log is not None:
         e1.record()
-        log.append(('deform_conv3x3 C=%d %dx%d s%d%s' % (c, ho, wo, stride, '' if offset is not None else ' (no offsets)'),
+        fn = _lib.lib().wd_deform_conv3x3_variant
+        fn.restype = C.c_char_p
+        name = fn(C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad), C.c_int(0 if offset is None else 1)).decode()
+        log.append(('%s: deform_conv3x3 C=%d %dx%d s%d%s' % (name, c, ho, wo, stride, '' if offset is not None else ' (no offsets)'),
                     2.0 * c * (c // groups) * 9 * ho * wo * n, e0, e1))
     return y
 
