@@ -422,9 +422,6 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_patch_kernel(
 //     samples whose corners leave the patch (|offset| > ~2 px) are flagged and read from global memory;
 //   * a wave owns (group, pixel range): it blends ITS channels of ITS pixels into a private slab and multiplies them,
 //     so the tap loop has no workgroup barrier; B operands of tap k+1 are requested before the MFMAs of tap k.
-#ifndef WD_DBG
-#define WD_DBG 0
-#endif
 constexpr int PST = PCH + 4;         // patch pixel stride in floats: 16 lanes reading 16 different pixels at the same
                                      // channel offset hit 16 different 4-bank groups (conflict-free ds_read_b128)
 template <int CG>
@@ -506,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
         e_gp[j] = gp;
         e_dy[j] = e_dx[j] = 0.f;
         e_m[j] = 1.f;
-        if (gp >= 0 && WD_DBG != 4) {
+        if (gp >= 0) {
             e_dy[j] = offset[(size_t)gp * 18 + 2 * k];
             e_dx[j] = offset[(size_t)gp * 18 + 2 * k + 1];
             if (mask) e_m[j] = mask[(size_t)gp * 9 + k];
@@ -523,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
             const int r = pp / PS, cc = pp - r * PS;
             const int iy = py0 + r, ix = px0 + cc;
             v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (WD_DBG != 3 && e < PS * PS * (PCH / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W)
+            if (e < PS * PS * (PCH / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W)
                 v[j] = *reinterpret_cast<const float4*>(x + ((size_t)(tn * H + iy) * W + ix) * C + c0 + q * 4);
         }
 #pragma unroll
@@ -573,15 +570,14 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
 
     auto mfma = [&](const float (&a)[MT][KS], const float (&b)[NT][KS]) {
 #pragma unroll
-        for (int kk = 0; kk < (WD_DBG == 1 ? 1 : KS); ++kk)
+        for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kk], b[nt][kk], acc[mt][nt], 0, 0, 0);
     };
-    if (WD_DBG == 8) {
-    } else if (!slow) {
+    if (!slow) {
         // Software pipeline inside the wave: the LDS reads of tap k+1 are issued BEFORE the MFMA burst of tap k and blended
         // after it has been issued, so corner latency and blend VALU run under the matrix pipe's 32-cycle instructions.
         // (Waves of a SIMD issue their MFMAs round-robin and stay in phase: without this, every wave gathers while the
@@ -615,16 +611,15 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
                     o[mt][4 * h + 3] = wv[mt].x * cv[mt][0][h].w + wv[mt].y * cv[mt][1][h].w + wv[mt].z * cv[mt][2][h].w + wv[mt].w * cv[mt][3][h].w;
                 }
         };
-        if (WD_DBG != 2) { gather_issue(0); blend(a[0]); }
+        gather_issue(0);
+        blend(a[0]);
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             if (k + 1 < 9) load_b(k + 1, bR[(k + 1) & 1]);
-            if (k + 1 < 9 && WD_DBG != 2) gather_issue(k + 1);
-            if (WD_DBG == 7) __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < 9) gather_issue(k + 1);
             mfma(a[k & 1], bR[k & 1]);
-            if (WD_DBG == 7) __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < 9 && WD_DBG != 2) blend(a[(k + 1) & 1]);
-            if (WD_DBG != 5 && WD_DBG != 7 && k + 1 < 9) {
+            if (k + 1 < 9) blend(a[(k + 1) & 1]);
+            if (k + 1 < 9) {
                 // interleave inside the MFMA burst (a wave issues in order: VALU / LDS instructions only overlap the matrix
                 // pipe when they sit BETWEEN two MFMAs): first the LDS reads of tap k+1, then its blend VALU
                 constexpr int NM = MT * NT * KS;            // MFMAs per tap (32 / 16)
