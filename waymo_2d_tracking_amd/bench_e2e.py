@@ -7,6 +7,7 @@ category) and written into the frame-slotted SoA layout of wt_track_streams_dev;
 runs as one wavefront of the persistent SORT kernel.  Nothing leaves the GPU inside the timed region.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -86,6 +87,21 @@ class DetectTrackPipeline(object):
         return total
 
 
+def _pmc_traffic(tag):
+    """HBM bytes per launch of the roofline kernel from the committed PMC pass (profiles/r01_e2e_pmc_traffic.json,
+    collected with tools/pmc_traffic.sh - counters cannot be read from inside the timed run); None if not recorded."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r01_e2e_pmc_traffic.json')
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for name, v in rec.items():
+        if tag.startswith(name):
+            return v.get('traffic_bytes_per_launch')
+    return None
+
+
 def run(args, world, rank, timed_steps):
     from .detnet.nn import ops
     fps = max(1, args.frames_per_step // 5)
@@ -120,7 +136,7 @@ def run(args, world, rank, timed_steps):
         cnt, ms, flops = deform[tag]
         ach = flops / (ms / cnt * 1e-3) / 1e12
         roofline = dict(bound='mfma', kernel=tag, achieved=ach, peak=157.3,
-                        unit='TFLOP/s', frac=ach / 157.3, traffic=None, launches=cnt, avg_us=ms / cnt * 1e3,
+                        unit='TFLOP/s', frac=ach / 157.3, traffic=_pmc_traffic(tag), launches=cnt, avg_us=ms / cnt * 1e3,
                         flops_per_launch=flops,
                         all_shapes={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, tflops=v[2] / (v[1] / v[0] * 1e-3) / 1e12)
                                     for k, v in by_shape.items()})
