@@ -92,13 +92,15 @@ int wd_roi_pool_fpn_bwd_f32(float* const* grad_feats, const int32_t* heights, co
                             int n_levels, int channels, int batch, const float* rois, int n_rois, int pooled, int min_level,
                             int canonical_level, float canonical_size, const float* grad_out, void* stream);
 /* Deformable conv backward building blocks (detectron2 deformable_im2col / col2im / col2im_coord restated):
- *   im2col : col[p][k][c] (p = N*Ho*Wo output pixels, k = 9 taps, c = C_in, NHWC order) from x and offset;
- *   col2im : dcol[p][k][c] -> dx (N,H,W,C) += and doffset (N,Ho,Wo,18) += (both zero-initialised by the caller).
- * The weight / column GEMMs between them (dW = col^T dY, dcol = dY W^T per group) are plain library GEMMs. */
-int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, int w, int c, int stride, int pad, float* col,
-                         void* stream);
-int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int stride,
-                         int pad, float* dx, float* doffset, void* stream);
+ *   im2col : col[g][p][k][ci] (g = group, p = N*Ho*Wo output pixels, k = 9 taps, ci = channel inside the group; group-major
+ *            so that the per-group GEMMs are strided-batched library GEMMs without permute copies; groups = 1 gives the
+ *            plain [p][k][c]) from x and offset;
+ *   col2im : dcol (same layout) -> dx (N,H,W,C) += and doffset (N,Ho,Wo,18) += (both zero-initialised by the caller).
+ * The weight / column GEMMs between them (dW[g] = dY[g]^T col[g], dcol[g] = dY[g] W[g]) are plain library GEMMs. */
+int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, int w, int c, int groups, int stride, int pad,
+                         float* col, void* stream);
+int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int groups,
+                         int stride, int pad, float* dx, float* doffset, void* stream);
 
 /* 3x3 convolution (pad 1) with few output channels as "library GEMM + shift-add" (the 18-channel offset conv in front of
  * every DeformConv, job.log:412): partial (N,H,W,ld) holds, per INPUT pixel, partial[tap*n_out + n] = sum_c x[c]*w[n][c][tap]

@@ -15,6 +15,6 @@ std = float(os.environ.get('OFF_STD', '0.5'))
 for name, C, H, W in (('res3', 512, 111, 160), ('res4', 1024, 56, 80), ('res5', 2048, 28, 40)):
     x = torch.randn(1, C, H, W, device='cuda').contiguous(memory_format=torch.channels_last)
     off = (torch.randn(1, 18, H, W, device='cuda') * std).contiguous(memory_format=torch.channels_last)
-    dcol = torch.randn(H * W, 9, C, device='cuda')
-    t = bench(lambda: ops.deform_col2im(dcol, x, off, 1, 1))
+    dcol = torch.randn(32, H * W, 9, C // 32, device='cuda')
+    t = bench(lambda: ops.deform_col2im(dcol, x, off, 1, 1, 32))
     print('%s C=%d %dx%d: col2im %.1f us (dcol %.0f MB)' % (name, C, H, W, t, dcol.numel() * 4 / 1e6), flush=True)

@@ -110,8 +110,15 @@ __device__ __forceinline__ Tap make_tap(const float* __restrict__ offset, long g
 }
 
 // col[p][k][c] = bilinear(x, p, k, c)   (c fastest: float4 per thread, C/4 consecutive threads per (p, k))
+// column layout (both directions): [group][pixel p][tap k][ci], group-major, so that the per-group GEMMs between im2col and
+// col2im are strided-batched library GEMMs on these buffers without any permute copy (groups = 1: the plain [p][k][c])
+__device__ __forceinline__ size_t col_index(long gp, int k, int c, long npix, int cg) {
+    const int g = c / cg, ci = c - g * cg;
+    return (((size_t)g * npix + gp) * 9 + k) * cg + ci;
+}
+
 __global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                            long npix, int Ho, int Wo, int H, int W, int C, int stride,
+                                                            long npix, int Ho, int Wo, int H, int W, int C, int cg, int stride,
                                                             int pad, float* __restrict__ col) {
     const int c4n = C >> 2;
     const long total = npix * 9 * c4n;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restr
             const float4 s = *reinterpret_cast<const float4*>(x + (size_t)t.idx[q] * C + c4 * 4);
             v.x += t.wgt[q] * s.x; v.y += t.wgt[q] * s.y; v.z += t.wgt[q] * s.z; v.w += t.wgt[q] * s.w;
         }
-        *reinterpret_cast<float4*>(col + (size_t)e * 4) = v;
+        *reinterpret_cast<float4*>(col + col_index(gp, k, c4 * 4, npix, cg)) = v;
     }
 }
 
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restr
 template <bool WITH_DX>
 __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restrict__ dcol, const float* __restrict__ x,
                                                             const float* __restrict__ offset, long npix, int Ho, int Wo,
-                                                            int H, int W, int C, int stride, int pad,
+                                                            int H, int W, int C, int cg, int stride, int pad,
                                                             float* __restrict__ dx, float* __restrict__ doffset) {
     const int c4n = C >> 2;                       // a multiple of 32 (C % 128 == 0): a wave never straddles two (p, k)
     const long total = npix * 9 * c4n;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
         const int k = (int)(pk % 9);
         const long gp = pk / 9;
         const Tap t = make_tap(offset, gp, k, Ho, Wo, H, W, stride, pad);
-        float4 g = act ? *reinterpret_cast<const float4*>(dcol + (size_t)ee * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = act ? *reinterpret_cast<const float4*>(dcol + col_index(gp, k, c4 * 4, npix, cg)) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
 // Samples whose corners leave the patch go to global memory directly.  doffset comes from deform_col2im_kernel<false>.
 constexpr int BT = 8, BPR = 2, BPS = BT + 2 + 2 * BPR, BCH = 64, BNE = BT * BT * 9;
 __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const float* __restrict__ dcol, const float* __restrict__ offset,
-                                                                      int batch, int Ho, int Wo, int H, int W, int C,
+                                                                      int batch, int Ho, int Wo, int H, int W, int C, int cg,
                                                                       float* __restrict__ dx) {
     __shared__ float4 tw[BNE];
     __shared__ int toff[BNE];                  // patch pixel of corner (hl, wl); < 0: packed image coordinates (global path)
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
             }
     }
     __syncthreads();
-    const float* __restrict__ dc = dcol + c0 + lane;
+    const float* __restrict__ dc = dcol + col_index(0, 0, c0 + lane, (long)batch * Ho * Wo, cg);   // + row * cg per entry
     for (int pp = wave; pp < BPS * BPS; pp += 4) {
         const int n0 = start[pp], n1 = start[pp + 1];
         const int r = pp / BPS, cc = pp - r * BPS;
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
             for (int u = 0; u < 16; ++u) {
                 const int j = (i + u < n1) ? i + u : n1 - 1;
                 wv[u] = (i + u < n1) ? ent_w[j] : 0.f;
-                g[u] = dc[(size_t)ent_row[j] * C];
+                g[u] = dc[(size_t)ent_row[j] * cg];
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc += wv[u] * g[u];
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
             const int off = toff[e];
             const int row = trow[e];
             if (off >= 0 || row < 0) continue;
-            const float g = dc[(size_t)row * C];
+            const float g = dc[(size_t)row * cg];
             const float4 w4 = tw[e];
             const float wq[4] = {w4.x, w4.y, w4.z, w4.w};
             const int code = -1 - off;
@@ -342,29 +349,32 @@ int wd_roi_pool_fpn_bwd_f32(float* const* grad_feats, const int32_t* heights, co
     return WT_OK;
 }
 
-static int check_deform(int c, int h, int w, int stride) {
-    if (c % 128 || h < 1 || w < 1 || stride < 1) { wt::set_error("deform backward: need C %% 128 == 0 (C=%d)", c); return WT_ERR_INVALID; }
+static int check_deform(int c, int groups, int h, int w, int stride) {
+    if (c % 128 || h < 1 || w < 1 || stride < 1 || groups < 1 || c % groups || (c / groups) % 4) {
+        wt::set_error("deform backward: need C %% 128 == 0 and (C / groups) %% 4 == 0 (C=%d groups=%d)", c, groups);
+        return WT_ERR_INVALID;
+    }
     return WT_OK;
 }
 
-int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, int w, int c, int stride, int pad, float* col,
-                         void* stream) {
+int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, int w, int c, int groups, int stride, int pad,
+                         float* col, void* stream) {
     WT_TRY(wt::ensure_device());
-    WT_TRY(check_deform(c, h, w, stride));
+    WT_TRY(check_deform(c, groups, h, w, stride));
     const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
     const long npix = (long)batch * ho * wo;
     const long total = npix * 9 * (c / 4);
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(deform_im2col_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
-                       x, offset, npix, ho, wo, h, w, c, stride, pad, col);
+                       x, offset, npix, ho, wo, h, w, c, c / groups, stride, pad, col);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
 
-int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int stride,
-                         int pad, float* dx, float* doffset, void* stream) {
+int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int groups,
+                         int stride, int pad, float* dx, float* doffset, void* stream) {
     WT_TRY(wt::ensure_device());
-    WT_TRY(check_deform(c, h, w, stride));
+    WT_TRY(check_deform(c, groups, h, w, stride));
     const int ho = (h + 2 * pad - 3) / stride + 1, wo = (w + 2 * pad - 3) / stride + 1;
     const long npix = (long)batch * ho * wo;
     const long total = npix * 9 * (c / 4);
@@ -373,13 +383,13 @@ int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset,
     if (stride == 1 && pad == 1 && !(mode && strcmp(mode, "atomic") == 0)) {
         // doffset (gather + channel reduction) and dx (inverted sampling table, gather) as two kernels
         hipLaunchKernelGGL(deform_col2im_kernel<false>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
-                           (hipStream_t)stream, dcol, x, offset, npix, ho, wo, h, w, c, stride, pad, dx, doffset);
+                           (hipStream_t)stream, dcol, x, offset, npix, ho, wo, h, w, c, c / groups, stride, pad, dx, doffset);
         const long nwg = (long)batch * ((ho + BT - 1) / BT) * ((wo + BT - 1) / BT) * (c / BCH);
         hipLaunchKernelGGL(deform_col2im_dx_gather_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, dcol, offset,
-                           batch, ho, wo, h, w, c, dx);
+                           batch, ho, wo, h, w, c, c / groups, dx);
     } else {
         hipLaunchKernelGGL(deform_col2im_kernel<true>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
-                           (hipStream_t)stream, dcol, x, offset, npix, ho, wo, h, w, c, stride, pad, dx, doffset);
+                           (hipStream_t)stream, dcol, x, offset, npix, ho, wo, h, w, c, c / groups, stride, pad, dx, doffset);
     }
     WT_HIP(hipGetLastError());
     return WT_OK;

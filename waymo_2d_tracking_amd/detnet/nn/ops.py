@@ -228,27 +228,28 @@ def preprocess(x, scale=1.0, hflip=False, vflip=False, swap_rb=True, mean=None, 
 
 # ---------------------------------------------------------------------------------------------------------------
 # training (fwd + bwd): autograd wrappers around the forward kernels and the backward kernels of det_backward.hip
-def deform_im2col(x, offset, stride=1, pad=1):
-    """col (P, 9, C) float32, P = N*Ho*Wo (detectron2 deformable_im2col, NHWC order)."""
+def deform_im2col(x, offset, stride=1, pad=1, groups=1):
+    """col (groups, P, 9, C/groups) float32, P = N*Ho*Wo (detectron2 deformable_im2col; group-major column layout)."""
     x = _nhwc(x); offset = _nhwc(offset)
     n, c, h, w = x.shape
     ho = (h + 2 * pad - 3) // stride + 1
     wo = (w + 2 * pad - 3) // stride + 1
-    col = torch.empty((n * ho * wo, 9, c), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().wd_deform_im2col_f32(_p(x), _p(offset), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(stride),
-                                               C.c_int(pad), _p(col), _stream()), 'wd_deform_im2col_f32')
+    col = torch.empty((groups, n * ho * wo, 9, c // groups), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().wd_deform_im2col_f32(_p(x), _p(offset), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups),
+                                               C.c_int(stride), C.c_int(pad), _p(col), _stream()), 'wd_deform_im2col_f32')
     return col
 
 
-def deform_col2im(dcol, x, offset, stride=1, pad=1):
-    """dcol (P, 9, C) -> (dx (N,C,H,W) channels_last, doffset (N,18,Ho,Wo) channels_last)."""
+def deform_col2im(dcol, x, offset, stride=1, pad=1, groups=1):
+    """dcol (groups, P, 9, C/groups) -> (dx (N,C,H,W) channels_last, doffset (N,18,Ho,Wo) channels_last)."""
     x = _nhwc(x); offset = _nhwc(offset)
     dcol = dcol.contiguous()
     n, c, h, w = x.shape
     dx = torch.zeros_like(x, memory_format=torch.channels_last)
     doff = torch.zeros_like(offset, memory_format=torch.channels_last)
     _lib.check(_lib.lib().wd_deform_col2im_f32(_p(dcol), _p(x), _p(offset), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
-                                               C.c_int(stride), C.c_int(pad), _p(dx), _p(doff), _stream()), 'wd_deform_col2im_f32')
+                                               C.c_int(groups), C.c_int(stride), C.c_int(pad), _p(dx), _p(doff), _stream()),
+               'wd_deform_col2im_f32')
     return dx, doff
 
 
@@ -265,20 +266,24 @@ class DeformConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        """im2col -> two strided-batched library GEMMs per layer -> col2im.  Columns are group-major (G, P, 9*Cg) and dy is
+        used through its (G, P, Cout/G) strided view, so no operand or result is permuted / copied in HBM."""
         x, offset, weight = ctx.saved_tensors
         groups, stride, pad = ctx.cfg
         cout, cg = weight.shape[0], weight.shape[1]
         cog = cout // groups
         dyn = _nhwc(dy).permute(0, 2, 3, 1)
         p = dyn.shape[0] * dyn.shape[1] * dyn.shape[2]
-        dym = dyn.reshape(p, groups, cog)
-        col = deform_im2col(x, offset, stride, pad).view(p, 9, groups, cg)
-        dw = torch.einsum('pgo,pkgi->goik', dym, col).reshape(cout, cg, 3, 3) if ctx.needs_input_grad[2] else None
-        dx = doff = None
+        dyg = dyn.reshape(p, groups, cog).permute(1, 0, 2)                      # (G, P, cog) view, row stride Cout
+        dx = doff = dw = None
+        if ctx.needs_input_grad[2]:
+            col = deform_im2col(x, offset, stride, pad, groups).view(groups, p, 9 * cg)
+            dwg = torch.bmm(dyg.transpose(1, 2), col)                           # (G, cog, 9*cg): [g][o][k][i]
+            dw = dwg.view(groups, cog, 9, cg).permute(0, 1, 3, 2).reshape(cout, cg, 3, 3)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            wg = weight.view(groups, cog, cg, 9)
-            dcol = torch.einsum('pgo,goik->pkgi', dym, wg).reshape(p, 9, groups * cg)
-            dx, doff = deform_col2im(dcol, x, offset, stride, pad)
+            wg = weight.view(groups, cog, cg, 9).permute(0, 1, 3, 2).reshape(groups, cog, 9 * cg)   # [g][o][k][i] (small)
+            dcol = torch.bmm(dyg, wg)                                           # (G, P, 9*cg)
+            dx, doff = deform_col2im(dcol, x, offset, stride, pad, groups)
         return dx, doff, dw, None, None, None
 
 
