@@ -193,14 +193,18 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
 // channel): 196 x 64 per workgroup instead of 2304 x 64.  (LDS float atomics were measured at ~250 cycles per wave
 // instruction on gfx950 - an LDS accumulator version of this kernel ran 1.1 ms against 2.2 ms for plain global atomics.)
 // Samples whose corners leave the patch go to global memory directly.  doffset comes from deform_col2im_kernel<false>.
-constexpr int BT = 8, BPR = 2, BPS = BT + 2 + 2 * BPR, BCH = 64, BNE = BT * BT * 9;
+constexpr int BT = 8, BPR = 2, BCH = 64, BNE = BT * BT * 9;
+template <int S>                             // S = stride (1 / 2): the input patch of a tile is ((BT-1)*S + 3 + 2*BPR)^2 pixels
 __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const float* __restrict__ dcol, const float* __restrict__ offset,
                                                                       int batch, int Ho, int Wo, int H, int W, int C, int cg,
                                                                       float* __restrict__ dx) {
+    constexpr int BPS = (BT - 1) * S + 3 + 2 * BPR;      // 14 / 21
+    constexpr int NPP = BPS * BPS;
+    constexpr int PER = (NPP + 63) / 64;                 // counts scanned per lane
     __shared__ float4 tw[BNE];
     __shared__ int toff[BNE];                  // patch pixel of corner (hl, wl); < 0: packed image coordinates (global path)
     __shared__ int trow[BNE];                  // dcol row (gp * 9 + k) of the entry, -1 = output pixel outside the image
-    __shared__ int cnt[BPS * BPS], start[BPS * BPS + 1], cursor[BPS * BPS];
+    __shared__ int cnt[NPP], start[NPP + 1], cursor[NPP];
     __shared__ int ent_row[BNE * 4];
     __shared__ float ent_w[BNE * 4];
     __shared__ int n_global;
@@ -214,8 +218,8 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
     const int trem = tile - tn * tiles_y * tiles_x;
     const int tyy = trem / tiles_x, txx = trem - tyy * tiles_x;
     const int c0 = chunk * BCH;
-    const int py0 = tyy * BT - 1 - BPR, px0 = txx * BT - 1 - BPR;          // image coordinates of patch pixel (0, 0)
-    if (tid < BPS * BPS) cnt[tid] = 0;
+    const int py0 = tyy * BT * S - 1 - BPR, px0 = txx * BT * S - 1 - BPR;  // image coordinates of patch pixel (0, 0)
+    for (int i = tid; i < NPP; i += 256) cnt[i] = 0;
     if (tid == 0) n_global = 0;
     __syncthreads();
     const int dq[4] = {0, 1, BPS, BPS + 1};
@@ -227,8 +231,8 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
         int off = 0;
         if (gp >= 0) {
             const int kh = k / 3, kw = k - 3 * kh;
-            const float ry = (float)((p >> 3) + kh + BPR) + offset[(size_t)gp * 18 + 2 * k];      // patch coordinates
-            const float rx = (float)((p & 7) + kw + BPR) + offset[(size_t)gp * 18 + 2 * k + 1];
+            const float ry = (float)((p >> 3) * S + kh + BPR) + offset[(size_t)gp * 18 + 2 * k];      // patch coordinates
+            const float rx = (float)((p & 7) * S + kw + BPR) + offset[(size_t)gp * 18 + 2 * k + 1];
             const float h_im = ry + (float)py0, w_im = rx + (float)px0;
             if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
                 const float fy = floorf(ry), fx = floorf(rx);
@@ -252,12 +256,12 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
         trow[e] = gp >= 0 ? gp * 9 + k : -1;
     }
     __syncthreads();
-    if (wave == 0) {                           // exclusive scan of the 196 counts (4 per lane + wave scan)
-        int c[4], s4 = 0;
+    if (wave == 0) {                           // exclusive scan of the patch-pixel counts (PER per lane + wave scan)
+        int c[PER], s4 = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = lane * 4 + j;
-            c[j] = idx < BPS * BPS ? cnt[idx] : 0;
+        for (int j = 0; j < PER; ++j) {
+            const int idx = lane * PER + j;
+            c[j] = idx < NPP ? cnt[idx] : 0;
             s4 += c[j];
         }
         int inc = s4;
@@ -268,12 +272,12 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
         }
         int base = inc - s4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = lane * 4 + j;
-            if (idx < BPS * BPS) { start[idx] = base; cursor[idx] = base; }
+        for (int j = 0; j < PER; ++j) {
+            const int idx = lane * PER + j;
+            if (idx < NPP) { start[idx] = base; cursor[idx] = base; }
             base += c[j];
         }
-        if (lane == 63) start[BPS * BPS] = inc;
+        if (lane == 63) start[NPP] = inc;
     }
     __syncthreads();
     for (int e = tid; e < BNE; e += 256) {
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
     }
     __syncthreads();
     const float* __restrict__ dc = dcol + col_index(0, 0, c0 + lane, (long)batch * Ho * Wo, cg);   // + row * cg per entry
-    for (int pp = wave; pp < BPS * BPS; pp += 4) {
+    for (int pp = wave; pp < NPP; pp += 4) {
         const int n0 = start[pp], n1 = start[pp + 1];
         const int r = pp / BPS, cc = pp - r * BPS;
         const int iy = py0 + r, ix = px0 + cc;
@@ -380,13 +384,17 @@ int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset,
     const long total = npix * 9 * (c / 4);
     const long blocks = (total + 255) / 256;
     const char* mode = getenv("WD_COL2IM");                 // experiments: "atomic" = one global atomic per corner value
-    if (stride == 1 && pad == 1 && !(mode && strcmp(mode, "atomic") == 0)) {
+    if ((stride == 1 || stride == 2) && pad == 1 && !(mode && strcmp(mode, "atomic") == 0)) {
         // doffset (gather + channel reduction) and dx (inverted sampling table, gather) as two kernels
         hipLaunchKernelGGL(deform_col2im_kernel<false>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
                            (hipStream_t)stream, dcol, x, offset, npix, ho, wo, h, w, c, c / groups, stride, pad, dx, doffset);
         const long nwg = (long)batch * ((ho + BT - 1) / BT) * ((wo + BT - 1) / BT) * (c / BCH);
-        hipLaunchKernelGGL(deform_col2im_dx_gather_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, dcol, offset,
-                           batch, ho, wo, h, w, c, c / groups, dx);
+        if (stride == 1)
+            hipLaunchKernelGGL(deform_col2im_dx_gather_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, dcol,
+                               offset, batch, ho, wo, h, w, c, c / groups, dx);
+        else
+            hipLaunchKernelGGL(deform_col2im_dx_gather_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, dcol,
+                               offset, batch, ho, wo, h, w, c, c / groups, dx);
     } else {
         hipLaunchKernelGGL(deform_col2im_kernel<true>, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
                            (hipStream_t)stream, dcol, x, offset, npix, ho, wo, h, w, c, c / groups, stride, pad, dx, doffset);
