@@ -85,6 +85,13 @@ int wd_preprocess_out_shape(int h, int w, double scale, int divisor, int* ho, in
 int wd_preprocess_f32(const void* src, int src_layout, int batch, int h, int w, double scale, int hflip, int vflip,
                       int swap_rb, const float* mean3, const float* std3, int divisor, float* out, void* stream);
 
+/* detectron2 Box2BoxTransform.apply_deltas (weights wx, wy, ww, wh; dw / dh clamped to scale_clamp = log(1000/16)) followed by
+ * Boxes.clip to [0, clip_w] x [0, clip_h] (clip_w <= 0: no clipping), one launch, arithmetic identical to the torch sequence.
+ *   deltas, boxes : (m, 4) float32, 16-byte aligned; index (n) int64 or NULL: row i uses deltas[index[i]], boxes[index[i]]
+ *   out           : (n, 4) float32 xyxy */
+int wd_decode_boxes_f32(const float* deltas, const float* boxes, const int64_t* index, int n, float wx, float wy, float ww,
+                        float wh, float scale_clamp, float clip_w, float clip_h, float* out, void* stream);
+
 /* ---- backward (training fwd+bwd) ---------------------------------------------------
  * ROIPooler backward: grad_out (R, pooled, pooled, C) is scattered (+=) into grad_feats[l] (same shapes as the
  * forward feats; the caller zero-initialises them).  grad_feats: HOST array of DEVICE pointers. */

@@ -301,3 +301,22 @@ def test_deform_conv_every_kernel_variant(monkeypatch, variant, C, off_std):
     exp = R.deform_conv3x3(x, offset, weight, 32, 1, 1, mask)
     got = ops.deform_conv3x3(_cl(x), _cl(offset), ops.deform_pack_weight(weight.cuda(), 32), 32, 1, 1, mask=_cl(mask))
     np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_decode_boxes_is_bit_identical_to_the_torch_sequence():
+    """wd_decode_boxes_f32 == apply_deltas + clip_boxes (detectron2 Box2BoxTransform / Boxes.clip restated in
+    cascade_rcnn.py), bit for bit, with and without gather index / clipping; huge dw hits the scale clamp."""
+    from waymo_2d_tracking_amd.detnet.nn.cascade_rcnn import apply_deltas, clip_boxes
+    g = torch.Generator().manual_seed(4)
+    m = 5000
+    xy = torch.rand(m, 2, generator=g) * 1500
+    boxes = torch.cat((xy, xy + torch.rand(m, 2, generator=g) * 400 + 1), 1).cuda()
+    deltas = (torch.randn(m, 4, generator=g) * torch.tensor([3.0, 3.0, 40.0, 40.0])).cuda()
+    idx = torch.randperm(m, generator=g)[:1777].cuda()
+    for w in ((1.0, 1.0, 1.0, 1.0), (10.0, 10.0, 5.0, 5.0), (30.0, 30.0, 15.0, 15.0)):
+        want = apply_deltas(deltas, boxes, w)
+        assert torch.equal(ops.decode_boxes(deltas, boxes, w), want)
+        assert torch.equal(ops.decode_boxes(deltas, boxes, w, None, (1280, 1920)), clip_boxes(want, 1280, 1920))
+        want_i = clip_boxes(apply_deltas(deltas[idx], boxes[idx], w), 886, 1280)
+        assert torch.equal(ops.decode_boxes(deltas, boxes, w, idx, (886, 1280)), want_i)
+    assert ops.decode_boxes(deltas[:0], boxes[:0], (1.0, 1.0, 1.0, 1.0)).shape == (0, 4)

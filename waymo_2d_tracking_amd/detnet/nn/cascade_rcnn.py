@@ -249,6 +249,12 @@ class RPN(nn.Module):
             self._anchors[key] = (shifts + cell.view(1, -1, 4)).reshape(-1, 4)     # (H*W*A, 4)
         return self._anchors[key]
 
+    def _level_ids(self, level, k, device):
+        key = (level, k, device)
+        if key not in self._anchors:
+            self._anchors[key] = torch.full((k,), level, dtype=torch.int32, device=device)
+        return self._anchors[key]
+
     def forward(self, feats, img_h, img_w):
         """feats p2..p6 (batch 1) -> proposals (R,4), sorted by objectness."""
         boxes_l, scores_l, lvl_l = [], [], []
@@ -261,10 +267,11 @@ class RPN(nn.Module):
             deltas = deltas.permute(0, 2, 3, 1).reshape(-1, 4)
             k = min(self.pre, logits.numel())
             top, idx = torch.topk(logits, k, sorted=True)
-            prop = apply_deltas(deltas[idx], self.anchors(l, h, w, f.device)[idx], (1.0, 1.0, 1.0, 1.0))
+            # apply_deltas(deltas[idx], anchors[idx]) + clip_boxes in one launch (wd_decode_boxes_f32, same arithmetic)
+            prop = ops.decode_boxes(deltas, self.anchors(l, h, w, f.device), (1.0, 1.0, 1.0, 1.0), idx, (img_h, img_w))
             boxes_l.append(prop); scores_l.append(top)
-            lvl_l.append(torch.full((k,), l, dtype=torch.int32, device=f.device))
-        boxes = clip_boxes(torch.cat(boxes_l), img_h, img_w)
+            lvl_l.append(self._level_ids(l, k, f.device))
+        boxes = torch.cat(boxes_l)
         scores = torch.cat(scores_l); lvls = torch.cat(lvl_l)
         ok = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
         boxes, scores, lvls = boxes[ok], scores[ok], lvls[ok]
@@ -358,14 +365,14 @@ class CascadeRCNN(nn.Module):
         stage_out = []
         boxes = proposals
         for k in range(3):
-            if k > 0:
-                boxes = clip_boxes(boxes, img_h, img_w)
             rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
             pooled = ops.roi_pool_fpn(feats[:4], rois, scales, 7, 2, 4, 224.0)
             logits, deltas = self.heads[k](pooled)
             stage_out.append((logits, deltas))
             stage_scores.append(F.softmax(logits, dim=-1))
-            boxes = apply_deltas(deltas, boxes, self.CASCADE_WEIGHTS[k])
+            # stages 0 / 1: the next stage starts with clip_boxes -> fused into the decode launch; the last stage's
+            # boxes stay unclipped for the isfinite filter of inference()
+            boxes = ops.decode_boxes(deltas, boxes, self.CASCADE_WEIGHTS[k], None, (img_h, img_w) if k < 2 else None)
         scores = (stage_scores[0] + stage_scores[1] + stage_scores[2]) * (1.0 / 3)
         if intermediates is not None:
             intermediates.update(feats=feats, proposals=proposals, stage_out=stage_out, boxes=boxes, scores=scores)

@@ -196,6 +196,23 @@ def conv3x3_few(x, w2, bias, n_out, stride=1):
     return out
 
 
+def decode_boxes(deltas, boxes, weights, index=None, clip=None, scale_clamp=4.135166556742356):
+    """apply_deltas(deltas[index], boxes[index], weights) [+ clip to (h, w)] in one launch; (n,4) float32 xyxy."""
+    deltas = deltas.contiguous().float()
+    boxes = boxes.contiguous().float()
+    n = deltas.shape[0] if index is None else index.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=deltas.device)
+    if n == 0:
+        return out
+    if index is not None:
+        index = index.contiguous().to(torch.int64)
+    ch, cw = (float(clip[0]), float(clip[1])) if clip is not None else (0.0, 0.0)
+    _lib.check(_lib.lib().wd_decode_boxes_f32(_p(deltas), _p(boxes), _p(index), C.c_int(n), C.c_float(weights[0]), C.c_float(weights[1]),
+                                              C.c_float(weights[2]), C.c_float(weights[3]), C.c_float(scale_clamp), C.c_float(cw),
+                                              C.c_float(ch), _p(out), _stream()), 'wd_decode_boxes_f32')
+    return out
+
+
 def preprocess_out_shape(h, w, scale=1.0, divisor=32):
     """(Ho, Wo, Hp, Wp) of preprocess(): resized extent and the extent padded to a multiple of `divisor`."""
     o = [C.c_int(0) for _ in range(4)]
