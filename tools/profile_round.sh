@@ -1,0 +1,18 @@
+#!/bin/bash
+# End-of-round evidence: default bench under rocprofv3 --kernel-trace --stats, steady-state per-frame / per-step breakdowns,
+# the plain bench lines of every stage.  Output: gpurun_out/round/ (copy what is to be judged into profiles/).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/round
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /tmp/prof_stats.log
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/e2e_kernel_stats.csv
+cd $R
+bash tools/e2e_profile.sh > /dev/null 2>&1; cp gpurun_out/e2e_steady.txt $OUT/e2e_steady_per_frame.txt
+bash tools/train_profile.sh > /dev/null 2>&1; cp gpurun_out/train_steady.txt $OUT/train_steady_per_step.txt
+python3 bench.py --steps 5 --warmup 2 > $OUT/e2e_bench_line.json 2>/dev/null
+python3 bench.py --stage train --steps 5 --warmup 3 --no-cpu-baseline > $OUT/train_bench_line.json 2>/dev/null
+python3 bench.py --stage track > $OUT/track_bench_line.json 2>/dev/null
+python3 bench.py --stage ensemble > $OUT/ensemble_bench_line.json 2>/dev/null
+python3 bench.py --stage detect --no-cpu-baseline > $OUT/detect_bench_line.json 2>/dev/null
+for f in $OUT/*_bench_line.json; do echo $f; tail -1 $f | cut -c1-170; done
