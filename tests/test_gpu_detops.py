@@ -320,3 +320,19 @@ def test_decode_boxes_is_bit_identical_to_the_torch_sequence():
         want_i = clip_boxes(apply_deltas(deltas[idx], boxes[idx], w), 886, 1280)
         assert torch.equal(ops.decode_boxes(deltas, boxes, w, idx, (886, 1280)), want_i)
     assert ops.decode_boxes(deltas[:0], boxes[:0], (1.0, 1.0, 1.0, 1.0)).shape == (0, 4)
+
+
+def test_roi_pool_whole_image_rois_take_the_direct_kernel():
+    """ROIs whose footprint exceeds 64 x 64 feature pixels on their level (whole-image boxes on p5) are flagged by the row
+    kernel and finished by the direct kernel; mixed with ordinary ROIs in one call."""
+    from oracle import detops_ref as R
+    g = torch.Generator().manual_seed(2)
+    strides = [4, 8, 16, 32]
+    H = W = 2560
+    C = 8
+    feats = [torch.randn((1, C, H // s, W // s), generator=g) for s in strides]
+    rois = torch.tensor([[0.0, 0.0, 0.0, 2560.0, 2560.0], [0.0, 100.0, 50.0, 2500.0, 2400.0], [0.0, 300.0, 300.0, 420.0, 380.0],
+                         [0.0, 1000.0, 1200.0, 1900.0, 1800.0]], dtype=torch.float32)
+    exp, lv = R.roi_pool_fpn(feats, rois, [1.0 / s for s in strides])
+    got = ops.roi_pool_fpn([_cl(f) for f in feats], rois.cuda(), [1.0 / s for s in strides])
+    np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=2e-5)
