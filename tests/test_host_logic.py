@@ -174,3 +174,19 @@ def test_tta_fused_pre_detection():
     assert mk('x1.5,x2')._fused_pre() is None
     with pytest.raises(NotImplementedError):
         mk('x1.5,brute')
+
+
+def test_packaged_gemm_tuning_file():
+    """waymo_2d_tracking_amd/tuning: the TunableOp selections shipped with the package parse (validator header + one
+    entry per GEMM signature) and enabling them without a GPU is a no-op."""
+    from waymo_2d_tracking_amd import tuning
+    lines = [l.strip().split(',') for l in open(tuning.PACKAGED) if l.strip()]
+    validators = [l for l in lines if l[0] == 'Validator']
+    entries = [l for l in lines if l[0] != 'Validator']
+    assert {v[1] for v in validators} >= {'PT_VERSION', 'HIPBLASLT_VERSION', 'GCN_ARCH_NAME'}
+    assert any('gfx950' in v[2] for v in validators)
+    assert len(entries) > 50 and all(len(e) == 4 and float(e[3]) > 0 for e in entries)
+    assert len({(e[0], e[1]) for e in entries}) == len(entries)
+    import torch
+    if not torch.cuda.is_available():
+        assert tuning.enable_gemm_tuning() is False

@@ -16,6 +16,7 @@ import torch
 from . import _lib
 from .detnet.nn.detectron2_det import Detectron2Det, detections_to_wire
 from .tracking.utils import make_params
+from .tuning import enable_gemm_tuning
 
 SLOTS = 100          # detectron2 TEST.DETECTIONS_PER_IMAGE (top-100, detectron2_det via fast_rcnn_inference)
 
@@ -25,6 +26,7 @@ class DetectTrackPipeline(object):
                  iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0):
         self.dev = torch.device(device)
         torch.backends.cudnn.benchmark = True      # the reference's --cudnn-benchmark: let MIOpen pick its fastest conv
+        enable_gemm_tuning()                       # ... and TunableOp its fastest library GEMM per 1x1-conv shape
         self.nc, self.fpc, self.h, self.w = n_cameras, frames_per_camera, height, width
         self.model = Detectron2Det(seed=seed).to(self.dev).eval()
         self.n_frames = n_cameras * frames_per_camera
@@ -157,6 +159,7 @@ def run_train(args, world, rank, timed_steps):
     from .detnet.nn import training
     from .detnet.nn.detectron2_det import Detectron2Det
     torch.backends.cudnn.benchmark = True
+    enable_gemm_tuning()
     dev = torch.device('cuda')
     det = Detectron2Det(seed=0).to(dev).train()
     params = training.set_trainable(det.model)

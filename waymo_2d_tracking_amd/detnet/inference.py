@@ -123,6 +123,9 @@ def inference(args):
     from . import nn as detnn
     from .. import distributed as D
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
+    if args.cudnn_benchmark:
+        from ..tuning import enable_gemm_tuning
+        enable_gemm_tuning()                       # library-GEMM counterpart of --cudnn-benchmark
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

@@ -1,0 +1,38 @@
+"""Library-GEMM selection for the detector's 1x1 convolutions / FC layers.
+
+The 1x1 convolutions of the NHWC backbone are plain library GEMMs (hipBLASLt / rocBLAS through torch).
+PyTorch's TunableOp times the candidate solutions of both libraries per GEMM shape and keeps the fastest; on MI355X that is
+worth ~6 % end-to-end over the default heuristic pick (bench.py: 24.1 -> 25.7 frames/s).  ``tunableop_gfx950.csv`` holds
+the selections measured on an MI355X with this image's torch / hipBLASLt build (``tools/tune_gemms.sh``); it is loaded
+when its validators (torch, ROCm, hipBLASLt, rocBLAS versions, gfx arch) match, and shapes missing from it are tuned online
+during warm-up (a few seconds, ``online=True``).  This is plumbing around library calls - the same role as the reference's
+``--cudnn-benchmark`` flag (detnet/inference.py:58).
+"""
+import os
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PACKAGED = os.path.join(HERE, 'tunableop_gfx950.csv')
+_done = False
+
+
+def enable_gemm_tuning(online=True, max_tuning_ms=15, max_iterations=30):
+    global _done
+    import torch
+    if _done or not torch.cuda.is_available():
+        return False
+    t = torch.cuda.tunable
+    t.enable(True)
+    t.set_max_tuning_duration(max_tuning_ms)
+    t.set_max_tuning_iterations(max_iterations)
+    # new selections of this process go to a scratch file (never into the package)
+    t.set_filename(os.environ.get('WT_TUNABLEOP_OUT', os.path.join(tempfile.gettempdir(), 'wt_tunableop_%d.csv' % os.getpid())))
+    loaded = False
+    if os.path.exists(PACKAGED):
+        try:
+            loaded = bool(t.read_file(PACKAGED))
+        except Exception:
+            loaded = False
+    t.tuning_enable(bool(online))
+    _done = True
+    return loaded
