@@ -477,12 +477,14 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
     const int ch_l = g_l * CG + kq * KS;                 // first channel (inside the chunk) this lane blends
     const int g = (c0 + g_l * CG) / CG;                  // global group
     float bR[2][NT][KS];
+    const float* __restrict__ wfrag = wp + (size_t)Cout * CG * 9 + ((size_t)g * 9 * 64 + lane) * (NT * KS);
     auto load_b = [&](int k, float (&b)[NT][KS]) {
+        const float4* src = reinterpret_cast<const float4*>(wfrag + (size_t)k * 64 * (NT * KS));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float* wb = wp + ((size_t)(g * 9 + k) * CG) * CG + 16 * nt + r16;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) b[nt][kk] = wb[(size_t)(kq * KS + kk) * CG];
+        for (int j = 0; j < NT * KS / 4; ++j) {
+            const float4 v = src[j];
+            b[(4 * j) / KS][(4 * j) % KS + 0] = v.x; b[(4 * j) / KS][(4 * j) % KS + 1] = v.y;
+            b[(4 * j) / KS][(4 * j) % KS + 2] = v.z; b[(4 * j) / KS][(4 * j) % KS + 3] = v.w;
         }
     };
     load_b(0, bR[0]);              // tap 0's weights: their L2 latency hides behind the patch fill and the table build
@@ -570,12 +572,13 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
 
     auto mfma = [&](const float (&a)[MT][KS], const float (&b)[NT][KS]) {
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
+        for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][kk], b[nt][kk], acc[mt][nt], 0, 0, 0);
+        }
     };
     if (!slow) {
         // Software pipeline inside the wave: the LDS reads of tap k+1 are issued BEFORE the MFMA burst of tap k and blended
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
                 constexpr int NM = MT * NT * KS;            // MFMAs per tap (32 / 16)
                 constexpr int NDS = MT * (2 + KS);          // LDS reads per tap
                 constexpr int H1 = NM / 4;
-                __builtin_amdgcn_sched_group_barrier(0x020, NT * KS, 0);      // B operands of tap k+1 first (oldest in vmcnt order)
+                __builtin_amdgcn_sched_group_barrier(0x020, NT * KS / 4, 0);   // B operand loads first (oldest in vmcnt order)
 #pragma unroll
                 for (int j = 0; j < H1; ++j) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -715,7 +718,17 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout
         const int ci = (int)((e / cg) % cg);
         const int k = (int)((e / ((long)cg * cg)) % 9);
         const int g = (int)(e / ((long)cg * cg * 9));
-        packed[e] = w[(((size_t)(g * cg + co) * cg) + ci) * 9 + k];
+        const float v = w[(((size_t)(g * cg + co) * cg) + ci) * 9 + k];
+        packed[e] = v;
+        // second copy, MFMA-B-fragment order of the LDS kernel (16 / 32 channels per group): lane (kq = ci / KS, r16 = co % 16)
+        // holds its NT x KS values contiguously, so a tap's B operands are NT*KS/4 dwordx4 loads per lane (1 KiB coalesced per
+        // wave instruction) instead of NT*KS strided dword loads
+        if (cg == 16 || cg == 32) {
+            const int KS = cg / 4, NT = cg / 16;
+            const int kq = ci / KS, kk = ci - kq * KS, nt = co >> 4, r16 = co & 15;
+            const int lane = kq * 16 + r16;
+            packed[total + (((size_t)(g * 9 + k) * 64 + lane) * NT + nt) * KS + kk] = v;
+        }
     }
 }
 
@@ -747,7 +760,7 @@ const char* wd_deform_conv3x3_variant(int c_in, int groups, int stride, int pad,
 
 size_t wd_deform_packed_weight_floats(int c_in, int c_out, int groups) {
     if (groups <= 0 || c_in % groups || c_in != c_out) return 0;
-    return (size_t)c_out * (size_t)(c_in / groups) * 9;
+    return 2 * (size_t)c_out * (size_t)(c_in / groups) * 9;      // [group][tap][ci][co] + the lane-major fragment copy
 }
 
 int wd_deform_pack_weight(const float* weight_oihw, int c_in, int c_out, int groups, float* packed, void* stream) {
