@@ -85,7 +85,7 @@ def test_grouped_conv_without_offsets(C, stride):
     np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('n', [1, 63, 64, 65, 500, 3000])
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 500, 3000, 4741, 6144, 6500])     # <= 6144: column sweep, above: row sweep
 def test_nms_vs_reference(n):
     from oracle import detops_ref as R
     from waymo_2d_tracking_amd.detnet.nn import ops
