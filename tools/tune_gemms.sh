@@ -7,7 +7,7 @@ mv waymo_2d_tracking_amd/tuning/tunableop_gfx950.csv /tmp/old_tunableop.csv 2>/d
 i=0
 for args in "--steps 2 --warmup 2" "--stage train --steps 2 --warmup 3" ; do
   i=$((i+1))
-  WT_TUNABLEOP_OUT=/tmp/wt_tune_$i.csv python3 bench.py $args --no-cpu-baseline | tail -1 | cut -c1-160
+  WT_GEMM_TUNING_ONLINE=1 WT_TUNABLEOP_OUT=/tmp/wt_tune_$i.csv python3 bench.py $args --no-cpu-baseline | tail -1 | cut -c1-160
 done
 python3 - <<'PY'
 import glob
