@@ -92,6 +92,16 @@ class ConvBN(nn.Module):
         self.stride, self.pad, self.groups = stride, pad, groups
 
     def forward(self, x, relu=False):
+        if not torch.is_grad_enabled() and self.weight.shape[0] % 4 == 0:
+            # inference: bias (+ReLU) in one vectorised NHWC pass behind the library conv instead of the framework's
+            # broadcast bias add (+ separate ReLU)
+            y = F.conv2d(x, self.weight, None, self.stride, self.pad, 1, self.groups)
+            if y.is_contiguous(memory_format=torch.channels_last):
+                n, c, h, w = y.shape
+                ops.bias_relu_(y.permute(0, 2, 3, 1).reshape(n * h * w, c), self.bias, relu)
+                return y
+            y = y + self.bias.view(1, -1, 1, 1)
+            return F.relu_(y) if relu else y
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.pad, 1, self.groups)
         return F.relu_(y) if relu else y
 
