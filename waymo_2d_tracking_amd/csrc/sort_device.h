@@ -293,9 +293,215 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Register variant for n, m <= 64 * RM / 64 * WM (the common case: <= 128 boxes per class and frame).  Same algorithm, same
+// visiting order and tie-breaks as munkres_wave below - only the storage differs: lane l keeps the zero bitmaps of ITS rows
+// (l, l + 64, ...) in VGPRs and the row / column covers are wave-uniform scalars, so the hot loop of step 4 ("first uncovered
+// zero in row-major order", executed O(n^2) times per frame) runs on ballots / readlanes / scalar bit operations with a single
+// LDS access (row_star) instead of ~6 dependent LDS round trips.
+template <int RM, int WM, class CostPtr>
+__device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMem& L) {
+    const int lane = threadIdx.x & 63;
+    const int W = (m + 63) >> 6, R = (n + 63) >> 6;
+    unsigned long long z[RM][WM];
+    unsigned long long cc[WM], rcov[RM];                      // wave-uniform cover bitmaps
+#pragma unroll
+    for (int j = 0; j < RM; ++j)
+#pragma unroll
+        for (int w = 0; w < WM; ++w) z[j][w] = 0ull;
+    for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;
+    // step 1: subtract row minima and build the zero bitmaps (row-parallel)
+#pragma unroll
+    for (int j = 0; j < RM; ++j) {
+        const int r = j * kWave + lane;
+        if (j < R && r < n) {
+            float mn = C[r * ld];
+            for (int c = 1; c < m; ++c) { const float v = C[r * ld + c]; mn = (v < mn) ? v : mn; }
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                if (w >= W) continue;
+                unsigned long long zz = 0ull;
+                const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                for (int c = 0; c < c1; ++c) {
+                    const float v = C[r * ld + 64 * w + c] - mn;
+                    C[r * ld + 64 * w + c] = v;
+                    zz |= (v == 0.f) ? (1ull << c) : 0ull;
+                }
+                z[j][w] = zz;
+            }
+            L.row_star[r] = -1;
+            L.row_prime[r] = -1;
+        }
+    }
+    __syncthreads();
+    // zero word w of row r (r wave-uniform)
+    auto zrow = [&](int r, int w) -> unsigned long long {
+        unsigned long long v = 0ull;
+#pragma unroll
+        for (int j = 0; j < RM; ++j)
+#pragma unroll
+            for (int ww = 0; ww < WM; ++ww)
+                if (j == (r >> 6) && ww == w) v = readlane64(z[j][ww], r & 63);
+        return v;
+    };
+    auto get = [&](const unsigned long long (&a)[WM], int w) -> unsigned long long {
+        unsigned long long v = 0ull;
+#pragma unroll
+        for (int ww = 0; ww < WM; ++ww) if (ww == w) v = a[ww];
+        return v;
+    };
+#pragma unroll
+    for (int w = 0; w < WM; ++w) cc[w] = 0ull;
+    // greedy stars in row-major order (serial over rows)
+    for (int r = 0; r < n; ++r) {
+        int first = -1;
+        for (int w = 0; w < W && first < 0; ++w) {
+            const unsigned long long a = zrow(r, w) & ~get(cc, w);
+            if (a) first = 64 * w + __builtin_ctzll(a);
+        }
+        if (first >= 0) {
+            if (lane == 0) { L.row_star[r] = first; L.col_star[first] = r; }
+#pragma unroll
+            for (int w = 0; w < WM; ++w) if (w == (first >> 6)) cc[w] |= 1ull << (first & 63);
+        }
+    }
+    __syncthreads();
+    long guard = 0;
+    const long guard_max = 64L + 8L * (long)(n + m) * (long)(n + m) * (long)(n + 1);
+    for (;;) {
+        // step 3: cover the starred columns; done when every row has a star
+        int stars = 0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+            cc[w] = 0ull;
+            if (w < W) {
+                const int c = 64 * w + lane;
+                cc[w] = __ballot((c < m) && L.col_star[c] >= 0);
+                stars += __popcll(cc[w]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RM; ++j) rcov[j] = 0ull;
+        if (stars >= n) return 0;
+        // step 4 (+ step 6)
+        int z0r = -1, z0c = -1;
+        for (;;) {
+            if (++guard > guard_max) return kErrNumeric;
+            int fr = -1, fc = -1;
+#pragma unroll
+            for (int j = 0; j < RM; ++j) {
+                if (j < R && fr < 0) {
+                    const int r = j * kWave + lane;
+                    bool has = false;
+                    if (r < n && !((rcov[j] >> lane) & 1ull)) {
+#pragma unroll
+                        for (int w = 0; w < WM; ++w) has = has || ((z[j][w] & ~cc[w]) != 0ull);    // z is 0 beyond W
+                    }
+                    const unsigned long long mask = __ballot(has);
+                    if (mask) fr = j * kWave + __builtin_ctzll(mask);
+                }
+            }
+            if (fr >= 0) {
+                for (int w = 0; w < W && fc < 0; ++w) {
+                    const unsigned long long a = zrow(fr, w) & ~get(cc, w);
+                    if (a) fc = 64 * w + __builtin_ctzll(a);
+                }
+            }
+            if (fr < 0) {
+                // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
+                float mn = __builtin_inff();
+                bool any_r = false, any_c = false;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    if (w >= W) continue;
+                    const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                    const unsigned long long valid = (c1 == 64) ? ~0ull : ((1ull << c1) - 1ull);
+                    any_c = any_c || ((~cc[w] & valid) != 0ull);
+                }
+#pragma unroll
+                for (int j = 0; j < RM; ++j) {
+                    if (j >= R) continue;
+                    const int r = j * kWave + lane;
+                    const bool unc = (r < n) && !((rcov[j] >> lane) & 1ull);
+                    any_r = any_r || (__ballot(unc) != 0ull);
+                    if (unc) {
+#pragma unroll
+                        for (int w = 0; w < WM; ++w) {
+                            if (w >= W) continue;
+                            unsigned long long todo = ~cc[w];
+                            const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                            if (c1 < 64) todo &= (1ull << c1) - 1ull;
+                            while (todo) {
+                                const int c = __builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                                const float v = C[r * ld + 64 * w + c];
+                                mn = (v < mn) ? v : mn;
+                            }
+                        }
+                    }
+                }
+                mn = wave_min_f(mn);
+                if (any_r && any_c) {
+#pragma unroll
+                    for (int j = 0; j < RM; ++j) {
+                        if (j >= R) continue;
+                        const int r = j * kWave + lane;
+                        if (r < n) {
+                            const bool rcv = (rcov[j] >> lane) & 1ull;
+#pragma unroll
+                            for (int w = 0; w < WM; ++w) {
+                                if (w >= W) continue;
+                                const unsigned long long cw = cc[w];
+                                const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                                unsigned long long zz = 0ull;
+                                for (int c = 0; c < c1; ++c) {
+                                    float v = C[r * ld + 64 * w + c];
+                                    const bool ccov = (cw >> c) & 1ull;
+                                    if (rcv || !ccov) {
+                                        if (rcv) v = v + mn;
+                                        if (!ccov) v = v - mn;
+                                        C[r * ld + 64 * w + c] = v;
+                                    }
+                                    zz |= (v == 0.f) ? (1ull << c) : 0ull;
+                                }
+                                z[j][w] = zz;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+            const int sc = uni(L.row_star[fr]);
+            if (lane == 0) L.row_prime[fr] = fc;
+            if (sc < 0) { z0r = fr; z0c = fc; break; }
+#pragma unroll
+            for (int j = 0; j < RM; ++j) if (j == (fr >> 6)) rcov[j] |= 1ull << (fr & 63);
+#pragma unroll
+            for (int w = 0; w < WM; ++w) if (w == (sc >> 6)) cc[w] &= ~(1ull << (sc & 63));
+        }
+        __syncthreads();
+        // step 5: augmenting path (serial, lane 0); then erase primes
+        if (lane == 0) {
+            int pr = z0r, pc = z0c;
+            for (long it = 0; it <= (long)n + m; ++it) {
+                const int r2 = L.col_star[pc];
+                L.row_star[pr] = pc;
+                L.col_star[pc] = pr;
+                if (r2 < 0) break;
+                pr = r2;
+                pc = L.row_prime[r2];
+            }
+        }
+        __syncthreads();
+        for (int r = lane; r < n; r += kWave) L.row_prime[r] = -1;
+        __syncthreads();
+    }
+}
+
 // C: n x m float32 with leading dimension ld (n <= m <= 4096), modified in place.  Returns 0 or kErrNumeric.
 template <class CostPtr>
 __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L) {
+    if (n <= 128 && m <= 128) return munkres_wave_reg<2, 2>(C, n, m, ld, L);
     const int lane = threadIdx.x & 63;
     const int W = (m + 63) >> 6;
     for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;
