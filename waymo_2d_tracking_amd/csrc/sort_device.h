@@ -658,6 +658,15 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
 
 // One frame of one tracker: sort.py:244-296.  Dets::get(k, float[4]) yields the k-th detection of this class
 // as the float32 row the reference builds (tracker_sort.py:45); Emit receives the rows of sort.py:286-288.
+#ifdef WT_PHASE_TIMING
+__device__ unsigned long long wt_phase[8];
+#define WT_T0 long long _t = clock64();
+#define WT_TICK(i) { const long long _n = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&wt_phase[i], (unsigned long long)(_n - _t)); _t = _n; }
+#else
+#define WT_T0
+#define WT_TICK(i)
+#endif
+
 template <class Dets, class Emit>
 __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresMem& L, float* lds_cost,
                             int lds_cost_cap, const Dets& dets, int N, double iou_thr, int max_age, int min_hits,
@@ -666,6 +675,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
     const unsigned long long lt = lanemask_lt();
     const int cap = M.cap;
     S.frame_count += 1;
+    WT_T0
     // ---- predict; tracks with a non-finite predicted box are dropped (sort.py:256-265) ----
     int T = 0;
     {
@@ -700,6 +710,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
     for (int i = lane; i < T; i += kWave) M.trk_match[i] = -1;
     for (int k = lane; k < N; k += kWave) M.det_match[k] = -1;
     __syncthreads();
+    WT_TICK(0)
     // ---- associate (sort.py:193-230) ----
     if (T > 0 && N > 0) {
         const bool transposed = T < N;                 // Munkres works on rows <= cols
@@ -708,20 +719,41 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
         const bool in_lds = (long)n * ld <= (long)lds_cost_cap;
         if (!in_lds && !M.cost_g) return kErrCapacity;
         float* C = in_lds ? lds_cost : M.cost_g;
-        for (int e = lane; e < n * m; e += kWave) {
-            const int r = e / m, c = e - r * m;
-            const int d = transposed ? c : r, t = transposed ? r : c;
-            float db[4];
-            dets.get(d, db);
-            double tb[4];
+        // lane = detection (its float32 row is fetched once: two dependent global loads), predicted track boxes are held
+        // lane-wise in registers and broadcast one by one with readlane: no memory access in the N x T inner loop
+        for (int dbase = 0; dbase < N; dbase += kWave) {
+            const int d = dbase + lane;
+            float db[4] = {0.f, 0.f, 0.f, 0.f};
+            if (d < N) dets.get(d, db);
+            for (int tbase = 0; tbase < T; tbase += kWave) {
+                const int tl = tbase + lane;
+                double tbx[4] = {0., 0., 0., 0.};
+                if (tl < T) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) tb[q] = M.pbox[q * cap + t];
-            const float v = (float)iou_det_trk(db, tb);              // stored float32 (sort.py:201,205)
-            C[r * ld + c] = -v;                                        // linear_assignment(-iou_matrix)
+                    for (int q = 0; q < 4; ++q) tbx[q] = M.pbox[q * cap + tl];
+                }
+                const int tcnt = (T - tbase) < kWave ? (T - tbase) : kWave;
+                for (int tt = 0; tt < tcnt; ++tt) {
+                    double tb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned long long bits = readlane64((unsigned long long)__double_as_longlong(tbx[q]), tt);
+                        tb[q] = __longlong_as_double((long long)bits);
+                    }
+                    const float v = (float)iou_det_trk(db, tb);      // stored float32 (sort.py:201,205)
+                    if (d < N) {
+                        const int t = tbase + tt;
+                        const int r = transposed ? t : d, c = transposed ? d : t;
+                        C[r * ld + c] = -v;                            // linear_assignment(-iou_matrix)
+                    }
+                }
+            }
         }
         __syncthreads();
+        WT_TICK(1)
         const int rc = in_lds ? munkres_wave(lds_cost, n, m, ld, L) : munkres_wave(M.cost_g, n, m, ld, L);
         if (rc) return rc;
+        WT_TICK(2)
         for (int d = lane; d < N; d += kWave) {
             const int t = transposed ? L.col_star[d] : L.row_star[d];
             if (t >= 0) {
@@ -741,6 +773,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
         }
         __syncthreads();
     }
+    WT_TICK(3)
     // ---- update matched tracks (sort.py:270-273) ----
     for (int i = lane; i < T; i += kWave) {
         const int d = M.trk_match[i];
@@ -753,6 +786,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
             kalman_update(M, slot, db);
         }
     }
+    WT_TICK(4)
     // ---- births (sort.py:276-278): never-assigned detections ascending, then threshold-rejected ones ----
     int nb = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -822,6 +856,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
     *n_births = nb;
     *n_rows = K;
     __syncthreads();
+    WT_TICK(5)
     return 0;
 }
 
