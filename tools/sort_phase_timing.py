@@ -11,11 +11,14 @@ try:
 except SystemExit:
     pass
 from waymo_2d_tracking_amd import _lib
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 12)()
 if not hasattr(_lib.lib(), 'wt_debug_phase_cycles'):
     sys.exit('library was not built with -DWT_PHASE_TIMING')
 _lib.lib().wt_debug_phase_cycles(out, 0)
 v = np.array(list(out), dtype=np.float64)
 names = ['predict', 'iou matrix', 'munkres', 'match filter', 'kalman update', 'births + emit + reap']
-for n, x in zip(names, v):
-    print('%-22s %5.1f %%' % (n, 100 * x / v.sum()))
+tot = v[:6].sum()
+for n, x in zip(names, v[:6]):
+    print('%-22s %5.1f %%' % (n, 100 * x / tot))
+for n, i in (('  munkres: step 1 + greedy stars', 6), ('  munkres: steps 3-5 (cover / prime / augment)', 8), ('  munkres: step 6 (adjust)', 7)):
+    print('%-46s %5.1f %%' % (n, 100 * v[i] / tot))

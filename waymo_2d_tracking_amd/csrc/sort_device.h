@@ -293,6 +293,15 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
+#ifdef WT_PHASE_TIMING
+__device__ unsigned long long wt_phase[12];
+#define WT_T0 long long _t = clock64();
+#define WT_TICK(i) { const long long _n = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&wt_phase[i], (unsigned long long)(_n - _t)); _t = _n; }
+#else
+#define WT_T0
+#define WT_TICK(i)
+#endif
+
 // Register variant for n, m <= 64 * RM / 64 * WM (the common case: <= 128 boxes per class and frame).  Same algorithm, same
 // visiting order and tie-breaks as munkres_wave below - only the storage differs: lane l keeps the zero bitmaps of ITS rows
 // (l, l + 64, ...) in VGPRs and the row / column covers are wave-uniform scalars, so the hot loop of step 4 ("first uncovered
@@ -308,6 +317,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
     for (int j = 0; j < RM; ++j)
 #pragma unroll
         for (int w = 0; w < WM; ++w) z[j][w] = 0ull;
+    WT_T0
     for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;
     // step 1: subtract row minima and build the zero bitmaps (row-parallel)
 #pragma unroll
@@ -365,6 +375,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
         }
     }
     __syncthreads();
+    WT_TICK(6)
     long guard = 0;
     const long guard_max = 64L + 8L * (long)(n + m) * (long)(n + m) * (long)(n + 1);
     for (;;) {
@@ -381,7 +392,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
         }
 #pragma unroll
         for (int j = 0; j < RM; ++j) rcov[j] = 0ull;
-        if (stars >= n) return 0;
+        if (stars >= n) { WT_TICK(8) return 0; }
         // step 4 (+ step 6)
         int z0r = -1, z0c = -1;
         for (;;) {
@@ -407,6 +418,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
                 }
             }
             if (fr < 0) {
+                WT_TICK(8)
                 // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
                 float mn = __builtin_inff();
                 bool any_r = false, any_c = false;
@@ -469,6 +481,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
                     }
                 }
                 __syncthreads();
+                WT_TICK(7)
                 continue;
             }
             const int sc = uni(L.row_star[fr]);
@@ -658,15 +671,6 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
 
 // One frame of one tracker: sort.py:244-296.  Dets::get(k, float[4]) yields the k-th detection of this class
 // as the float32 row the reference builds (tracker_sort.py:45); Emit receives the rows of sort.py:286-288.
-#ifdef WT_PHASE_TIMING
-__device__ unsigned long long wt_phase[8];
-#define WT_T0 long long _t = clock64();
-#define WT_TICK(i) { const long long _n = clock64(); if ((threadIdx.x & 63) == 0) atomicAdd(&wt_phase[i], (unsigned long long)(_n - _t)); _t = _n; }
-#else
-#define WT_T0
-#define WT_TICK(i)
-#endif
-
 template <class Dets, class Emit>
 __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresMem& L, float* lds_cost,
                             int lds_cost_cap, const Dets& dets, int N, double iou_thr, int max_age, int min_hits,

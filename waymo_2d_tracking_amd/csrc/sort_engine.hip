@@ -475,9 +475,9 @@ int wt_track_streams_host(int64_t n_dets, const double* x, const double* y, cons
 
 #ifdef WT_PHASE_TIMING
 // experiments only (-DWT_PHASE_TIMING): cycles per tracker_step phase summed over all waves
-extern "C" int wt_debug_phase_cycles(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(wtdev::wt_phase), 64) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(wtdev::wt_phase), z, 64); }
+extern "C" int wt_debug_phase_cycles(unsigned long long* out12, int reset) {
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(wtdev::wt_phase), 96) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[12] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(wtdev::wt_phase), z, 96); }
     return 0;
 }
 #endif
