@@ -422,6 +422,10 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_patch_kernel(
 //     samples whose corners leave the patch (|offset| > ~2 px) are flagged and read from global memory;
 //   * a wave owns (group, pixel range): it blends ITS channels of ITS pixels into a private slab and multiplies them,
 //     so the tap loop has no workgroup barrier; B operands of tap k+1 are requested before the MFMAs of tap k.
+// tile pixel p (0..63) -> row: a 16-pixel M tile is rows (t, t + 4) x 8 columns, t = p >> 4.  With the 14-pixel patch pitch two
+// ADJACENT rows land on bank groups shifted by 2 (6 of 16 lanes of a ds_read_b128 service group collide); rows 4 apart are
+// shifted by 8 and share none.
+#define PROW(p) (((p) >> 4) + 4 * (((p) >> 3) & 1))
 constexpr int PST = PCH + 4;         // patch pixel stride in floats: 16 lanes reading 16 different pixels at the same
                                      // channel offset hit 16 different 4-bank groups (conflict-free ds_read_b128)
 template <int CG>
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
     const int py0 = tyy * 8 - 1 - PR, px0 = txx * 8 - 1 - PR;       // image coordinates of patch pixel (0, 0)
     if (tid == 0) any_fb = 0;
     if (tid < TP) {
-        const int ho = tyy * 8 + (tid >> 3), wo = txx * 8 + (tid & 7);
+        const int ho = tyy * 8 + PROW(tid), wo = txx * 8 + (tid & 7);
         pix[tid] = (ho < Ho && wo < Wo) ? (tn * Ho + ho) * Wo + wo : -1;
     }
     // MFMA A fragments are blended straight into registers: lane (row r = lane & 15, kq = lane >> 4) owns pixel r of each
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
         const int p = e / 9, k = e - 9 * p;
         int gp = -1;
         if (e < TP * 9) {
-            const int ho = tyy * 8 + (p >> 3), wo = txx * 8 + (p & 7);
+            const int ho = tyy * 8 + PROW(p), wo = txx * 8 + (p & 7);
             gp = (ho < Ho && wo < Wo) ? (tn * Ho + ho) * Wo + wo : -1;
         }
         e_gp[j] = gp;
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void deform_conv3x3_lds_kernel(
         int off = 0;
         if (e_gp[j] >= 0) {
             const int kh = k / 3, kw = k - 3 * kh;
-            const float ry = (float)((p >> 3) + kh + PR) + e_dy[j];        // patch coordinates
+            const float ry = (float)(PROW(p) + kh + PR) + e_dy[j];        // patch coordinates
             const float rx = (float)((p & 7) + kw + PR) + e_dx[j];
             const float h_im = ry + (float)py0, w_im = rx + (float)px0;
             const float m = e_m[j];
