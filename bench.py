@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument('--images', type=int, default=990, help='ensemble stage: images per GPU')
     ap.add_argument('--k-inputs', type=int, default=13)
     ap.add_argument('--frames-per-step', type=int, default=10, help='e2e/detect: frames per step (multiple of 5)')
+    ap.add_argument('--tta', default='', help="e2e/detect: test-time augmentation of the detector pass, e.g. x1.5,hflip (config 4)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 

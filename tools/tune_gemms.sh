@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mv waymo_2d_tracking_amd/tuning/tunableop_gfx950.csv /tmp/old_tunableop.csv 2>/dev/null
 i=0
-for args in "--steps 2 --warmup 2" "--stage train --steps 2 --warmup 3" ; do
+for args in "--steps 2 --warmup 2" "--stage train --steps 2 --warmup 3" "--stage detect --tta x1.5,hflip --steps 2 --warmup 2" ; do
   i=$((i+1))
   WT_GEMM_TUNING_ONLINE=1 WT_TUNABLEOP_OUT=/tmp/wt_tune_$i.csv python3 bench.py $args --no-cpu-baseline | tail -1 | cut -c1-160
 done

@@ -23,8 +23,17 @@ SLOTS = 100          # detectron2 TEST.DETECTIONS_PER_IMAGE (top-100, detectron2
 
 class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
-                 iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0):
+                 iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta=''):
         self.dev = torch.device(device)
+        # --tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image, folded into the pre-processing kernel
+        self.tta_scale, self.tta_hflip = 1.0, False
+        for aug in [a for a in tta.split(',') if a]:
+            if aug.startswith('x'):
+                self.tta_scale *= float(aug[1:])
+            elif aug == 'hflip':
+                self.tta_hflip = True
+            elif aug != 'orig':
+                raise ValueError('bench supports --tta orig / xS / hflip, got %r' % aug)
         torch.backends.cudnn.benchmark = True      # the reference's --cudnn-benchmark: let MIOpen pick its fastest conv
         enable_gemm_tuning()                       # ... and TunableOp its fastest library GEMM per 1x1-conv shape
         self.nc, self.fpc, self.h, self.w = n_cameras, frames_per_camera, height, width
@@ -57,8 +66,11 @@ class DetectTrackPipeline(object):
     def detect_frame(self, f):
         """Frame f (camera-major order) -> wire-format detections written into slots [f*100, f*100+100)."""
         # decoded uint8 HWC RGB frame -> fused pre-processing kernel (ToTensor(scaling=False) + BGR + normalise + pad)
-        (boxes, scores, classes), = self.model.predict_device(self.frames[f:f + 1])
-        xywh, score, cat = detections_to_wire(boxes, scores, classes, self.w, self.h)
+        (boxes, scores, classes), = self.model.predict_device(self.frames[f:f + 1], self.tta_scale, self.tta_hflip)
+        ho, wo = self.model.last_input_size
+        if self.tta_hflip:                                                      # HFlipTTA.post_process: cx <- 1 - cx
+            boxes = torch.stack((wo - boxes[:, 2], boxes[:, 1], wo - boxes[:, 0], boxes[:, 3]), dim=1)
+        xywh, score, cat = detections_to_wire(boxes, scores, classes, wo, ho, self.w, self.h)
         k = xywh.shape[0]
         a = f * SLOTS
         self.category[a:a + SLOTS] = 0                                          # unused slots: category 0 = ignored
@@ -107,7 +119,7 @@ def _pmc_traffic(tag):
 def run(args, world, rank, timed_steps):
     from .detnet.nn import ops
     fps = max(1, args.frames_per_step // 5)
-    pipe = DetectTrackPipeline(5, fps, seed=rank)
+    pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '')
     steps = args.steps or 3
     warmup = args.warmup if args.warmup is not None else 1
     track = args.stage == 'e2e'
@@ -143,9 +155,10 @@ def run(args, world, rank, timed_steps):
                         all_shapes={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, tflops=v[2] / (v[1] / v[0] * 1e-3) / 1e12)
                                     for k, v in by_shape.items()})
     res = dict(value=frames * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, dtype='f32',
-               workload='Cascade R-CNN X152-32x8d-FPN dconv (random-init, fp32, batch 1) on synthetic 1920x1280x3 frames'
+               workload='Cascade R-CNN X152-32x8d-FPN dconv (random-init, fp32, batch 1%s) on synthetic 1920x1280x3 frames'
                         ' -> top-100 detections/frame -> %s; %d cameras x %d frames per step per GPU'
-                        % ('SORT (max_age 2, min_hits 0, all boxes tracked)' if track else 'no tracking', 5, fps),
+                        % (', --tta ' + args.tta if getattr(args, 'tta', '') else '',
+                           'SORT (max_age 2, min_hits 0, all boxes tracked)' if track else 'no tracking', 5, fps),
                roofline=roofline,
                extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births))
     res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters

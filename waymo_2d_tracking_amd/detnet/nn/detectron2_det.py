@@ -85,7 +85,7 @@ class Detectron2Det(Module):
         return output[0] if single else output
 
 
-def detections_to_wire(boxes, scores, classes, width, height):
+def detections_to_wire(boxes, scores, classes, width, height, out_width=None, out_height=None):
     """Device-side twin of Detectron2Det.predict (:119-131) + COCODetection.load_prediction
     (/root/reference/detnet/data/coco.py:229-252): the [x, y, w, h] integers, 5-decimal score and category id that
     the detection JSON carries between inference.py and tracking/track.py.  float32 box arithmetic, float64 scaling
@@ -96,7 +96,9 @@ def detections_to_wire(boxes, scores, classes, width, height):
     bx[:, 1::2] *= 1.0 / height
     center = (bx[:, :2] + bx[:, 2:]) / 2
     wh = bx[:, 2:4] - bx[:, 0:2]
-    scale = torch.tensor([width, height], dtype=torch.float64, device=boxes.device)
+    # TTA: the boxes are normalised in the transformed (resized) image and scaled by the ORIGINAL size (tta.py: boxes are
+    # normalised, so ResizeTTA needs no undo; coco.py:249 multiplies by the image's own width / height)
+    scale = torch.tensor([out_width or width, out_height or height], dtype=torch.float64, device=boxes.device)
     c64 = center.double() * scale
     wh64 = wh.double() * scale
     lt = c64 - wh64 / 2
