@@ -374,10 +374,17 @@ class CascadeRCNN(nn.Module):
         stage_scores = []
         stage_out = []
         boxes = proposals
+        # the number of proposals is data dependent; the box heads run on a row count rounded up to a multiple of 64 (zero
+        # boxes, sliced off again) so that the library convolutions / GEMMs see a small fixed set of shapes - with
+        # cudnn.benchmark every NEW shape costs a solver search
+        n_roi = boxes.shape[0]
+        n_pad = (-n_roi) % 64 if n_roi else 0
         for k in range(3):
-            rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
+            rois = torch.zeros((n_roi + n_pad, 5), dtype=torch.float32, device=boxes.device)
+            rois[:n_roi, 1:] = boxes
             pooled = ops.roi_pool_fpn(feats[:4], rois, scales, 7, 2, 4, 224.0)
             logits, deltas = self.heads[k](pooled)
+            logits, deltas = logits[:n_roi], deltas[:n_roi]
             stage_out.append((logits, deltas))
             stage_scores.append(F.softmax(logits, dim=-1))
             # stages 0 / 1: the next stage starts with clip_boxes -> fused into the decode launch; the last stage's
