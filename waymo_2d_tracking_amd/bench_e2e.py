@@ -42,10 +42,17 @@ class DetectTrackPipeline(object):
         g = torch.Generator(device='cpu').manual_seed(seed)
         self.frames = torch.randint(0, 256, (self.n_frames, height, width, 3), generator=g, dtype=torch.uint8).to(self.dev)
         n = self.n_frames * SLOTS
-        self.x = torch.zeros(n, dtype=torch.float64, device=self.dev)
-        self.y = torch.zeros_like(self.x); self.wd = torch.zeros_like(self.x); self.ht = torch.zeros_like(self.x)
-        self.score = torch.zeros_like(self.x)
-        self.category = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        # two sets of detection slots: SORT over chunk s runs on its own stream while the detector fills the slots of
+        # chunk s + 1 (the tracker kernel is one wave per (camera, class) - it would leave the other CUs idle)
+        self._slots = []
+        for _ in range(2):
+            x = torch.zeros(n, dtype=torch.float64, device=self.dev)
+            self._slots.append(dict(x=x, y=torch.zeros_like(x), wd=torch.zeros_like(x), ht=torch.zeros_like(x),
+                                    score=torch.zeros_like(x), category=torch.zeros(n, dtype=torch.int32, device=self.dev)))
+        self._cur = 0
+        self._bind(0)
+        self.track_stream = torch.cuda.Stream(device=self.dev)
+        self._track_done = None
         self.frame_off = (torch.arange(self.n_frames + 1, dtype=torch.int64) * SLOTS).to(self.dev)
         self.stream_off = (torch.arange(n_cameras + 1, dtype=torch.int64) * frames_per_camera).to(self.dev)
         self.clip_w = torch.full((n_cameras,), float(width), dtype=torch.float64, device=self.dev)
@@ -62,6 +69,11 @@ class DetectTrackPipeline(object):
         self.out_id = torch.empty(n + 1, dtype=torch.int64, device=self.dev)
         self.counts = torch.zeros(2, dtype=torch.int64, device=self.dev)
         self.n_dets_last = 0
+
+    def _bind(self, i):
+        self._cur = i
+        for k, v in self._slots[i].items():
+            setattr(self, k, v)
 
     def detect_frame(self, f):
         """Frame f (camera-major order) -> wire-format detections written into slots [f*100, f*100+100)."""
@@ -96,7 +108,19 @@ class DetectTrackPipeline(object):
         for f in range(self.n_frames):
             total += self.detect_frame(f)
         if with_tracking:
-            self.track()
+            main = torch.cuda.current_stream()
+            filled = torch.cuda.Event()
+            filled.record(main)
+            with torch.cuda.stream(self.track_stream):
+                self.track_stream.wait_event(filled)             # slots of this chunk are complete
+                self.track()                                     # reads the slot set bound during detection
+                self._track_done = torch.cuda.Event()
+                self._track_done.record(self.track_stream)
+            self._bind(1 - self._cur)                            # the next chunk's detections go to the other set
+            # the set being re-bound was consumed by the track() of the previous step on the same (in-order) stream,
+            # i.e. before the track() just queued; the detector may only overwrite it after that one has finished
+            main.wait_event(self._prev_done) if getattr(self, '_prev_done', None) is not None else None
+            self._prev_done = self._track_done
         self.n_dets_last = total
         return total
 
