@@ -374,11 +374,11 @@ class CascadeRCNN(nn.Module):
         stage_scores = []
         stage_out = []
         boxes = proposals
-        # the number of proposals is data dependent; the box heads run on a row count rounded up to a multiple of 64 (zero
+        # the number of proposals is data dependent; the box heads run on a row count rounded up to a multiple of 32 (zero
         # boxes, sliced off again) so that the library convolutions / GEMMs see a small fixed set of shapes - with
         # cudnn.benchmark every NEW shape costs a solver search
         n_roi = boxes.shape[0]
-        n_pad = (-n_roi) % 64 if n_roi else 0
+        n_pad = (-n_roi) % 32 if n_roi else 0
         for k in range(3):
             rois = torch.zeros((n_roi + n_pad, 5), dtype=torch.float32, device=boxes.device)
             rois[:n_roi, 1:] = boxes
