@@ -190,3 +190,19 @@ def test_packaged_gemm_tuning_file():
     import torch
     if not torch.cuda.is_available():
         assert tuning.enable_gemm_tuning() is False
+
+
+def test_detections_to_wire_tta_scaling():
+    """Device-side wire conversion: boxes of a resized (TTA x1.5) pass are normalised by the transformed size and scaled by
+    the ORIGINAL size (boxes are normalised in the reference: tta.py ResizeTTA.post_process is the identity), integer
+    truncation and 5-decimal scores as in coco.py:249-251."""
+    import torch
+    from waymo_2d_tracking_amd.detnet.nn.detectron2_det import detections_to_wire
+    boxes = torch.tensor([[150.0, 300.0, 450.9, 600.3], [0.0, 0.0, 2880.0, 1920.0]])
+    scores = torch.tensor([0.123456, 0.999994])
+    classes = torch.tensor([0, 3])
+    xywh, score, cat = detections_to_wire(boxes, scores, classes, 2880, 1920, 1920, 1280)
+    assert xywh.tolist() == [[100.0, 200.0, 200.0, 200.0], [0.0, 0.0, 1920.0, 1280.0]]
+    assert [round(v, 5) for v in score.tolist()] == [0.12346, 0.99999] and cat.tolist() == [1, 4]
+    same, _, _ = detections_to_wire(boxes, scores, classes, 2880, 1920)
+    assert same.tolist() == [[150.0, 300.0, 300.0, 300.0], [0.0, 0.0, 2880.0, 1920.0]]
