@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument('--frames-per-step', type=int, default=10, help='e2e/detect: frames per step (multiple of 5)')
     ap.add_argument('--tta', default='', help="e2e/detect: test-time augmentation of the detector pass, e.g. x1.5,hflip (config 4)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-verify', action='store_true', help='skip the oracle replay of the timed output (after the timed region)')
     return ap.parse_args()
 
 
@@ -153,24 +154,49 @@ def stage_track(args, world, rank):
                                   'reported for completeness, not as the limiter'),
                extra=dict(n_dets=n_dets, n_rows=rows, n_births=births, n_frames=n_frames))
     res['roofline']['frac'] = res['roofline']['achieved'] / HBM_PEAK_GBS
+    if rank == 0 and not args.no_verify:
+        # checker, outside the timed region: the rows of the timed call replayed through the CPU oracle
+        from oracle import oracle as O
+        O.build()
+        ref = O.track_streams(packed, 2, 0, sthr, ithr)
+        res['verified'] = dict(ok=bool(births == ref['n_births'] and np.array_equal(out['object_id'], ref['object_id'])
+                                       and np.array_equal(out['frame'], ref['frame']) and np.array_equal(out['bbox'], ref['bbox'])),
+                               rows=rows, rows_ref=int(len(ref['frame'])), against='oracle/sort_oracle.c on the same detections')
     if rank == 0 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline_track(ithr, sthr)
     return res, steps, warmup
 
 
 def cpu_baseline_track(ithr, sthr):
+    """The C oracle on the host cores: one thread, then one thread per core with the segments spread over the threads
+    (streams are independent apart from the id offsets, exactly like the GPU sharding) - SURVEY 8d (ii)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build()
     packed = build_predictions(1000, 1)
     t0 = time.perf_counter()
     reps = 0
-    while time.perf_counter() - t0 < 10.0:
+    while time.perf_counter() - t0 < 6.0:
         O.track_streams(packed, 2, 0, sthr, ithr)
         reps += 1
     dt = time.perf_counter() - t0
-    return dict(value=reps * 990 / dt, unit='frames/s', cores=1, kind='port',
-                sample='oracle/sort_oracle.c (C restatement of tracking/sort), 1 segment x 5 cameras x 198 frames, '
-                       '%d repetitions, single thread' % reps)
+    single = reps * 990 / dt
+    cores = os.cpu_count() or 1
+    n_thr = min(cores, 128)
+    per_thread = max(1, int(round(single * 6.0 / 990)))          # ~6 s of work per thread at the single-thread rate
+
+    def work(_):
+        for _ in range(per_thread):
+            O.track_streams(packed, 2, 0, sthr, ithr)            # ctypes releases the GIL inside the C call
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(n_thr) as ex:
+        list(ex.map(work, range(n_thr)))
+    dtm = time.perf_counter() - t0
+    return dict(value=n_thr * per_thread * 990 / dtm, unit='frames/s', cores=n_thr, kind='port',
+                single_thread=single,
+                sample='oracle/sort_oracle.c (C restatement of tracking/sort): 1 segment x 5 cameras x 198 frames per '
+                       'call; %d calls on one thread (%.0f frames/s), then %d threads x %d calls (one segment per thread, '
+                       'the way the GPU path shards streams)' % (reps, single, n_thr, per_thread))
 
 
 def build_groups(seed, n_images, k_inputs, n_objects=100):
@@ -205,6 +231,18 @@ def stage_ensemble(args, world, rank):
                              peak=HBM_PEAK_GBS, unit='GB/s', traffic=None),
                extra=dict(n_rows=int(len(d)), n_groups=int(len(off) - 1)))
     res['roofline']['frac'] = res['roofline']['achieved'] / HBM_PEAK_GBS
+    if rank == 0 and not args.no_verify:
+        import torch
+        from oracle import oracle as O
+        O.build()
+        torch.cuda.synchronize()
+        got, counts = ens.out5[:len(d)].cpu().numpy(), ens.counts[:len(off) - 1].cpu().numpy()
+        exp, ecounts = O.ensemble_groups(d, off, sizes, args.k_inputs, 2, 0.5, 0.9)
+        ok = bool(np.array_equal(counts, ecounts)) and all(
+            np.array_equal(got[int(off[g]):int(off[g]) + int(counts[g])], exp[int(off[g]):int(off[g]) + int(counts[g])])
+            for g in range(len(off) - 1))
+        res['verified'] = dict(ok=ok, groups=int(len(off) - 1), rows=int(counts.sum()),
+                               against='oracle/softnms_oracle.c on the same groups, bit-exact')
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as O
         O.build()
@@ -277,6 +315,13 @@ def main():
         from waymo_2d_tracking_amd import bench_e2e
         res, steps, warmup = bench_e2e.run(args, world, rank, timed_steps)
         pipe = res.pop('pipeline')
+        if rank == 0 and args.stage == 'e2e' and not args.no_verify:
+            # checker, outside the timed region: every detection the resident trackers consumed during this segment
+            # (warm-up and timed steps) replayed through the CPU oracle, rows / ids / boxes compared
+            from oracle import oracle as O
+            O.build()
+            res['verified'] = dict(bench_e2e.check_against(pipe, O.track_streams),
+                                   against='oracle/sort_oracle.c replay of the slots the timed steps filled')
         if rank == 0 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline_e2e(pipe, args.stage == 'e2e')
         metric = 'end-to-end frames/sec (detect+SORT) on 1920x1280 Waymo frames' if args.stage == 'e2e' else \
@@ -289,7 +334,8 @@ def main():
                 'warmup': warmup, 'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': res['dtype'], 'data': 'synthetic',
                 'config': {'workload': res['workload'], 'stage': args.stage, 'parallelism': 'sequence-shard x%d' % world},
-                'roofline': res.get('roofline'), 'cpu_baseline': res.get('cpu_baseline'), 'extra': res.get('extra')}
+                'roofline': res.get('roofline'), 'cpu_baseline': res.get('cpu_baseline'), 'verified': res.get('verified'),
+                'extra': res.get('extra')}
         print(json.dumps(line), flush=True)
     if _dist_on():
         import torch.distributed as dist

@@ -137,6 +137,38 @@ int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const
                          int64_t* out_object_id, int64_t* n_out_dev, int64_t* n_births_dev,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Streaming form of the same tracker (online detect -> track: tracking/utils.py:29-36 keeps ONE MultiClassTrackerSort per
+ * stream alive while the frames arrive).  The trackers of n_streams streams live in a caller-owned device block `state`;
+ * every wt_track_chunk_dev call feeds the next frames of each stream (same SoA / CSR layout as wt_track_streams_dev; a
+ * stream may have zero frames in a chunk) and continues exactly where the previous chunk stopped, so that the rows of all
+ * chunks together equal ONE wt_track_streams_dev call over the concatenated frames (tests/test_gpu_sort.py).
+ *   out_frame     : frame index inside THIS chunk's CSR;
+ *   out_local_id  : 0-based ordinal of the track's birth inside its stream (over all chunks).  The reference's object id
+ *                   (process-global counter, sort.py:86,140-141) is id_base + births of the streams in front + ordinal + 1
+ *                   and is known once those streams are complete: wt_track_global_ids_dev does that conversion for any
+ *                   set of collected rows (row_stream = stream index of each row; stream_birth_prefix = n_streams + 1
+ *                   int64 of device scratch, receives the exclusive prefix sum of births per stream).
+ * max_frame_dets and params must be the same for every call on one state. */
+size_t wt_track_state_bytes(int32_t n_streams, int64_t max_frame_dets, const wt_track_params* params);
+int wt_track_state_init_dev(void* state, size_t state_bytes, int32_t n_streams, int64_t max_frame_dets,
+                            const wt_track_params* params, void* stream);
+size_t wt_track_chunk_workspace(int64_t n_dets, int64_t n_frames, int32_t n_streams, int64_t max_frame_dets,
+                                const wt_track_params* params);
+int wt_track_chunk_dev(void* state, size_t state_bytes,
+                       int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
+                       const double* score, const int32_t* category,
+                       int64_t n_frames, const int64_t* frame_det_offsets,
+                       int32_t n_streams, const int64_t* stream_frame_offsets,
+                       const double* clip_w, const double* clip_h, int64_t max_frame_dets,
+                       const wt_track_params* params,
+                       int64_t* out_frame, int32_t* out_category, double* out_bbox4, double* out_score,
+                       int64_t* out_local_id, int64_t* n_out_dev, int64_t* n_births_dev,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int wt_track_global_ids_dev(const void* state, size_t state_bytes, int32_t n_streams, int64_t max_frame_dets,
+                            const wt_track_params* params, int64_t n_rows, const int32_t* row_stream,
+                            const int64_t* local_id, int64_t id_base, int64_t* out_object_id,
+                            int64_t* stream_birth_prefix, void* stream);
+
 /* Native COCO-JSON I/O around the tracking stage (host code).
  * wt_detfile_read = json.load + read_data_file (tracking/utils.py:63-96: "annotations" wrapper, w/h < 1 and
  * per-class score filters, frame keys kept for fully filtered frames, missing score = 1.0) + the stream / frame

@@ -1,0 +1,213 @@
+"""The TIMED paths of bench.py against the CPU oracle: the device-resident (`*_dev`) entry points, the streaming tracker
+(wt_track_state_* / wt_track_chunk_dev) and the whole DetectTrackPipeline (detector -> wire conversion -> frame-slotted
+layout with category-0 holes -> SORT on a side stream -> per-segment history).  IDs / order / boxes bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_rows_equal(got, ref, births=None):
+    assert np.array_equal(got['object_id'], ref['object_id'])
+    assert np.array_equal(got['frame'], ref['frame'])
+    assert np.array_equal(got['category'], ref['category'])
+    assert np.array_equal(got['bbox'], ref['bbox'])
+    np.testing.assert_allclose(got['score'], ref['score'], rtol=4e-16, atol=0)
+    if births is not None:
+        assert births == ref['n_births']
+
+
+def _with_holes(packed, rng, slots):
+    """Re-lay a packed set of streams into fixed `slots`-wide frames with category-0 holes at random positions
+    (the layout the end-to-end pipeline feeds to wt_track_streams_dev / wt_track_chunk_dev)."""
+    nf = packed['frame_det_offsets'].size - 1
+    out = {k: np.zeros(nf * slots, dtype=packed[k].dtype) for k in ('x', 'y', 'w', 'h', 'score', 'category')}
+    fo = packed['frame_det_offsets']
+    for f in range(nf):
+        k = int(fo[f + 1] - fo[f])
+        assert k <= slots
+        pos = np.sort(rng.choice(slots, size=k, replace=False)) + f * slots
+        for key in out:
+            out[key][pos] = packed[key][fo[f]:fo[f + 1]]
+    holes = dict(packed)
+    holes.update(out)
+    holes['frame_det_offsets'] = (np.arange(nf + 1, dtype=np.int64) * slots)
+    return holes
+
+
+def _synthetic_packed(seed, n_segments=2, n_frames=25, n_objects=30):
+    from waymo_2d_tracking_amd import synthetic as syn
+    from waymo_2d_tracking_amd.tracking import utils as T
+    dets = syn.make_sequence_json(seed, n_segments=n_segments, n_frames=n_frames, n_objects=n_objects)
+    predictions = {}
+    for e in dets:
+        seg, fr, cam = e['image_id'].split('/')
+        predictions.setdefault(seg, {}).setdefault(cam, {}).setdefault(int(fr), []).append(
+            {'bbox': e['bbox'], 'score': e['score'], 'category_id': e['category_id']})
+    return T.pack_streams(predictions)
+
+
+def test_track_streams_dev_with_category0_holes(oracle):
+    """wt_track_streams_dev on the slotted layout (category 0 = empty slot) == oracle on the compacted detections."""
+    from waymo_2d_tracking_amd.devpath import DeviceTracker
+    sthr, ithr = [0.3, 0.2, 1.0, 0.1], [0.01, 0.01, 1.0, 0.0]
+    packed = _synthetic_packed(7)
+    ref = oracle.track_streams(packed, 2, 0, sthr, ithr)
+    holes = _with_holes(packed, np.random.default_rng(0), 64)
+    trk = DeviceTracker(holes, ithr, 2, 0, sthr)
+    trk.run()
+    out, births = trk.results()
+    _assert_rows_equal(out, ref, births)
+    assert len(out['frame']) > 500
+
+
+@pytest.mark.parametrize('chunk_frames', [1, 3, 7])
+def test_streaming_chunks_equal_one_shot(oracle, chunk_frames):
+    """Feeding the frames of every stream chunk by chunk through the resident trackers == one pass over all frames
+    (ids through wt_track_global_ids_dev), incl. streams that run out of frames before the others."""
+    import torch
+    from waymo_2d_tracking_amd.devpath import StreamingTracker
+    sthr, ithr = [0.3, 0.2, 1.0, 0.1], [0.01, 0.01, 1.0, 0.0]
+    packed = _synthetic_packed(11, n_segments=1, n_frames=20, n_objects=25)
+    # ragged: drop the last frames of some streams
+    so, fo = packed['stream_frame_offsets'], packed['frame_det_offsets']
+    ns = so.size - 1
+    lens = [int(so[s + 1] - so[s]) - (s % 3) * 2 for s in range(ns)]
+    keep_frames = np.concatenate([np.arange(so[s], so[s] + lens[s]) for s in range(ns)])
+    sel = np.concatenate([np.arange(fo[f], fo[f + 1]) for f in keep_frames]) if len(keep_frames) else np.zeros(0, int)
+    rag = {k: packed[k][sel] for k in ('x', 'y', 'w', 'h', 'score', 'category')}
+    cnt = np.diff(fo)[keep_frames]
+    rag['frame_det_offsets'] = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    rag['stream_frame_offsets'] = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rag['clip_w'], rag['clip_h'] = packed['clip_w'], packed['clip_h']
+    ref = oracle.track_streams(rag, 2, 0, sthr, ithr, id_base=100)
+    max_frame = int(cnt.max())
+    dev = torch.device('cuda')
+    trk = StreamingTracker(ns, max_frame, ns * chunk_frames, ns * chunk_frames * max_frame, ithr, 2, 0, sthr)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    cw, ch = t(rag['clip_w'], torch.float64), t(rag['clip_h'], torch.float64)
+    rows = {k: [] for k in ('frame', 'stream', 'category', 'bbox', 'score', 'lid')}
+    births = 0
+    rso, rfo = rag['stream_frame_offsets'], rag['frame_det_offsets']
+    for c0 in range(0, max(lens), chunk_frames):
+        fr_idx, s_off = [], [0]
+        for s in range(ns):
+            a = min(c0, lens[s]); b = min(c0 + chunk_frames, lens[s])
+            fr_idx += list(range(rso[s] + a, rso[s] + b))
+            s_off.append(len(fr_idx))
+        dsel = np.concatenate([np.arange(rfo[f], rfo[f + 1]) for f in fr_idx]) if fr_idx else np.zeros(0, int)
+        f_off = np.concatenate([[0], np.cumsum([rfo[f + 1] - rfo[f] for f in fr_idx])]).astype(np.int64)
+        n = len(dsel)
+        of = torch.zeros(n + 1, dtype=torch.int64, device=dev); oc = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        ob = torch.zeros((n + 1, 4), dtype=torch.float64, device=dev); osc = torch.zeros(n + 1, dtype=torch.float64, device=dev)
+        oi = torch.zeros(n + 1, dtype=torch.int64, device=dev); cn = torch.zeros(2, dtype=torch.int64, device=dev)
+        trk.feed(t(rag['x'][dsel], torch.float64), t(rag['y'][dsel], torch.float64), t(rag['w'][dsel], torch.float64),
+                 t(rag['h'][dsel], torch.float64), t(rag['score'][dsel], torch.float64), t(rag['category'][dsel], torch.int32),
+                 t(f_off, torch.int64), t(np.asarray(s_off), torch.int64), cw, ch, of, oc, ob, osc, oi, cn)
+        k, nb = [int(v) for v in cn.cpu().tolist()]
+        assert k >= 0
+        births += nb
+        lf = of[:k].cpu().numpy()
+        gf = np.asarray(fr_idx, np.int64)[lf] if k else np.zeros(0, np.int64)
+        rows['frame'].append(gf)
+        rows['stream'].append(np.searchsorted(rso, gf, side='right') - 1)
+        rows['category'].append(oc[:k].cpu().numpy()); rows['bbox'].append(ob[:k].cpu().numpy())
+        rows['score'].append(osc[:k].cpu().numpy()); rows['lid'].append(oi[:k].cpu().numpy())
+    rows = {k: np.concatenate(v) for k, v in rows.items()}
+    gid = trk.global_ids(t(rows['stream'], torch.int32), t(rows['lid'], torch.int64), 100).cpu().numpy()
+    order = np.argsort(rows['stream'], kind='stable')
+    got = dict(frame=rows['frame'][order], category=rows['category'][order], bbox=rows['bbox'][order],
+               score=rows['score'][order], object_id=gid[order])
+    _assert_rows_equal(got, ref, births)
+
+
+def test_streaming_golden_g4(golden_dir):
+    """The reference-generated G4 fixture through the streaming tracker, 5 frames per chunk."""
+    import torch
+    from waymo_2d_tracking_amd.devpath import StreamingTracker
+    from waymo_2d_tracking_amd.tracking import utils as T
+    exp = json.load(open(os.path.join(golden_dir, 'sort_g4_expected_a.json')))
+    p = exp['params']
+    predictions = T.read_data_file(os.path.join(golden_dir, 'sort_g4_input.json'), p['score_threshold'])
+    packed = T.pack_streams(predictions)
+    so, fo = packed['stream_frame_offsets'], packed['frame_det_offsets']
+    ns = so.size - 1
+    lens = np.diff(so)
+    max_frame = int(np.diff(fo).max())
+    CH = 5
+    dev = torch.device('cuda')
+    trk = StreamingTracker(ns, max_frame, ns * CH, ns * CH * max_frame, p['iou_threshold'], p['max_age'], p['min_hits'],
+                           p['score_threshold'])
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    cw, ch = t(packed['clip_w'], torch.float64), t(packed['clip_h'], torch.float64)
+    acc = {k: [] for k in ('frame', 'stream', 'category', 'bbox', 'score', 'lid')}
+    for c0 in range(0, int(lens.max()), CH):
+        fr_idx, s_off = [], [0]
+        for s in range(ns):
+            fr_idx += list(range(so[s] + min(c0, lens[s]), so[s] + min(c0 + CH, lens[s])))
+            s_off.append(len(fr_idx))
+        dsel = np.concatenate([np.arange(fo[f], fo[f + 1]) for f in fr_idx]).astype(np.int64)
+        f_off = np.concatenate([[0], np.cumsum([fo[f + 1] - fo[f] for f in fr_idx])]).astype(np.int64)
+        n = len(dsel)
+        of = torch.zeros(n + 1, dtype=torch.int64, device=dev); oc = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        ob = torch.zeros((n + 1, 4), dtype=torch.float64, device=dev); osc = torch.zeros(n + 1, dtype=torch.float64, device=dev)
+        oi = torch.zeros(n + 1, dtype=torch.int64, device=dev); cn = torch.zeros(2, dtype=torch.int64, device=dev)
+        trk.feed(*[t(packed[k][dsel], torch.float64) for k in ('x', 'y', 'w', 'h', 'score')], t(packed['category'][dsel], torch.int32),
+                 t(f_off, torch.int64), t(np.asarray(s_off), torch.int64), cw, ch, of, oc, ob, osc, oi, cn)
+        k = int(cn[0].item())
+        gf = np.asarray(fr_idx, np.int64)[of[:k].cpu().numpy()]
+        acc['frame'].append(gf); acc['stream'].append(np.searchsorted(so, gf, side='right') - 1)
+        acc['category'].append(oc[:k].cpu().numpy()); acc['bbox'].append(ob[:k].cpu().numpy())
+        acc['score'].append(osc[:k].cpu().numpy()); acc['lid'].append(oi[:k].cpu().numpy())
+    acc = {k: np.concatenate(v) for k, v in acc.items()}
+    gid = trk.global_ids(t(acc['stream'], torch.int32), t(acc['lid'], torch.int64), 0).cpu().numpy()
+    order = np.argsort(acc['stream'], kind='stable')
+    out = dict(frame=acc['frame'][order], category=acc['category'][order], bbox=acc['bbox'][order],
+               score=acc['score'][order], object_id=gid[order])
+    got = T.format_tracks(packed, out)
+    rows = lambda tr: [(r['image_id'], r['category_id'], r['object_id']) for r in tr]
+    assert rows(got) == rows(exp['tracks'])
+    gb = np.array([r['bbox'] + [r['score']] for r in got]); eb = np.array([r['bbox'] + [r['score']] for r in exp['tracks']])
+    np.testing.assert_allclose(gb, eb, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('method,k_inputs', [(2, 3), (2, 13), (1, 3), (0, 3)])
+def test_ensemble_groups_dev_vs_oracle(oracle, method, k_inputs):
+    """wt_ensemble_groups_dev (the entry point bench.py --stage ensemble times) bit-exact against the oracle."""
+    import bench
+    from waymo_2d_tracking_amd.devpath import DeviceEnsemble
+    d, off, sizes = bench.build_groups(5, 12, k_inputs, n_objects=60)
+    ens = DeviceEnsemble(d, off, sizes, k_inputs, method, 0.5, 0.9)
+    ens.run()
+    import torch
+    torch.cuda.synchronize()
+    got = ens.out5[:len(d)].cpu().numpy()
+    counts = ens.counts[:len(off) - 1].cpu().numpy()
+    exp, ecounts = oracle.ensemble_groups(d, off, sizes, k_inputs, method, 0.5, 0.9)
+    assert np.array_equal(counts, ecounts)
+    for g in range(len(off) - 1):
+        a, n = int(off[g]), int(counts[g])
+        assert np.array_equal(got[a:a + n], exp[a:a + n]), g
+
+
+def test_detect_track_pipeline_vs_oracle(oracle):
+    """bench.py's DetectTrackPipeline (small frames, random-init detector): >= 3 steps on the side stream, a segment
+    wrap (trackers reset, slots reused), each time the rows of the whole segment equal the oracle's replay."""
+    import torch
+    from waymo_2d_tracking_amd.bench_e2e import DetectTrackPipeline, check_against
+    pipe = DetectTrackPipeline(n_cameras=5, frames_per_camera=2, height=256, width=384, seed=3, segment_frames=8,
+                               distinct_times=6)
+    for _ in range(3):
+        pipe.step(True)
+    rep = check_against(pipe, oracle.track_streams)
+    assert rep['ok'], rep
+    assert rep['chunks'] == 3 and rep['frames'] == 30 and rep['rows'] > 0
+    pipe.step(True)                     # chunk 4 of 4
+    rep = check_against(pipe, oracle.track_streams)
+    assert rep['ok'] and rep['chunks'] == 4, rep
+    pipe.step(True); pipe.step(True)    # wrap: new segment, chunks 1-2
+    rep = check_against(pipe, oracle.track_streams)
+    assert rep['ok'] and rep['chunks'] == 2 and pipe.segments_done == 1, rep

@@ -74,7 +74,8 @@ def lib():
         _lib.wt_mct_tracker.restype = C.c_void_p
         _lib.wt_mct_tracker.argtypes = [C.c_void_p, C.c_int]
         _lib.wt_sort_num_tracks.argtypes = [C.c_void_p]
-        for name in ('wt_track_streams_workspace', 'wt_ensemble_groups_workspace'):
+        for name in ('wt_track_streams_workspace', 'wt_ensemble_groups_workspace', 'wt_track_state_bytes',
+                     'wt_track_chunk_workspace'):
             getattr(_lib, name).restype = C.c_size_t
         for name in ('wd_workspace_bytes',):
             if hasattr(_lib, name):

@@ -3,8 +3,13 @@
 One step = one 5-camera chunk: `frames_per_step` synthetic 1920x1280x3 uint8 frames already resident in HBM go
 through the Cascade R-CNN X152-FPN detector one by one (batch 1, like the reference's --batch-size=1); their <= 100
 detections per frame are converted on the device to the detection-JSON wire values (int box, 5-decimal score,
-category) and written into the frame-slotted SoA layout of wt_track_streams_dev; then every (camera, class) tracker
-runs as one wavefront of the persistent SORT kernel.  Nothing leaves the GPU inside the timed region.
+category) and written into the frame-slotted SoA layout of wt_track_chunk_dev; then every (camera, class) tracker -
+resident in HBM for the whole segment, like the reference's one MultiClassTrackerSort per stream (tracking/utils.py:29)
+- consumes the chunk as one wavefront of the persistent SORT kernel.  Nothing leaves the GPU inside the timed region.
+
+Every chunk of the current segment keeps its own detection slots and output rows (a 198-frame segment is ~9 MB), so
+after a run `history()` hands the exact detections the tracker saw and the rows it produced to a checker
+(tests/test_gpu_e2e.py and bench.py replay them through the CPU oracle).
 """
 import ctypes as C
 import os
@@ -15,15 +20,29 @@ import torch
 
 from . import _lib
 from .detnet.nn.detectron2_det import Detectron2Det, detections_to_wire
-from .tracking.utils import make_params
+from .devpath import StreamingTracker
 from .tuning import enable_gemm_tuning
 
 SLOTS = 100          # detectron2 TEST.DETECTIONS_PER_IMAGE (top-100, detectron2_det via fast_rcnn_inference)
+SEGMENT_FRAMES = 198  # frames of one Waymo segment per camera: the trackers are reset after that many
+
+
+def moving_frames(n_cameras, n_times, height, width, seed, device):
+    """Synthetic camera streams already resident in HBM: per camera a uint8 U{0..255} image that translates
+    by (2, 3) px per frame, so consecutive frames of a stream show the same content moved - detections of consecutive
+    frames overlap the way tracked objects do, instead of being independent draws.  Layout [time][camera], HWC."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    base = torch.randint(0, 256, (n_cameras, height, width, 3), generator=g, dtype=torch.uint8).to(device)
+    out = torch.empty((n_times, n_cameras, height, width, 3), dtype=torch.uint8, device=device)
+    for t in range(n_times):
+        out[t] = torch.roll(base, shifts=(2 * t, 3 * t), dims=(1, 2))
+    return out
 
 
 class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
-                 iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta=''):
+                 iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta='',
+                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None):
         self.dev = torch.device(device)
         # --tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image, folded into the pre-processing kernel
         self.tta_scale, self.tta_hflip = 1.0, False
@@ -37,92 +56,155 @@ class DetectTrackPipeline(object):
         torch.backends.cudnn.benchmark = True      # the reference's --cudnn-benchmark: let MIOpen pick its fastest conv
         enable_gemm_tuning()                       # ... and TunableOp its fastest library GEMM per 1x1-conv shape
         self.nc, self.fpc, self.h, self.w = n_cameras, frames_per_camera, height, width
-        self.model = Detectron2Det(seed=seed).to(self.dev).eval()
+        self.model = model if model is not None else Detectron2Det(seed=seed).to(self.dev).eval()
         self.n_frames = n_cameras * frames_per_camera
-        g = torch.Generator(device='cpu').manual_seed(seed)
-        self.frames = torch.randint(0, 256, (self.n_frames, height, width, 3), generator=g, dtype=torch.uint8).to(self.dev)
+        self.n_times = max(frames_per_camera, (distinct_times // frames_per_camera) * frames_per_camera)
+        self.frames = moving_frames(n_cameras, self.n_times, height, width, seed, self.dev)
+        self.max_chunks = max(1, segment_frames // frames_per_camera)
         n = self.n_frames * SLOTS
-        # two sets of detection slots: SORT over chunk s runs on its own stream while the detector fills the slots of
-        # chunk s + 1 (the tracker kernel is one wave per (camera, class) - it would leave the other CUs idle)
-        self._slots = []
-        for _ in range(2):
-            x = torch.zeros(n, dtype=torch.float64, device=self.dev)
-            self._slots.append(dict(x=x, y=torch.zeros_like(x), wd=torch.zeros_like(x), ht=torch.zeros_like(x),
-                                    score=torch.zeros_like(x), category=torch.zeros(n, dtype=torch.int32, device=self.dev)))
-        self._cur = 0
-        self._bind(0)
-        self.track_stream = torch.cuda.Stream(device=self.dev)
-        self._track_done = None
+        self.chunk_dets = n
+        R = self.max_chunks
+        f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=self.dev)
+        # per-chunk detection slots (chunk-major; inside a chunk camera-major frames x 100 slots, category 0 = empty)
+        self.x, self.y, self.wd, self.ht, self.score = f64(R, n), f64(R, n), f64(R, n), f64(R, n), f64(R, n)
+        self.category = torch.zeros((R, n), dtype=torch.int32, device=self.dev)
+        # per-chunk tracker output rows
+        self.out_frame = torch.zeros((R, n + 1), dtype=torch.int64, device=self.dev)
+        self.out_cat = torch.zeros((R, n + 1), dtype=torch.int32, device=self.dev)
+        self.out_bbox = f64(R, n + 1, 4)
+        self.out_score = f64(R, n + 1)
+        self.out_id = torch.zeros((R, n + 1), dtype=torch.int64, device=self.dev)
+        self.chunk_counts = torch.zeros((R, 2), dtype=torch.int64, device=self.dev)
         self.frame_off = (torch.arange(self.n_frames + 1, dtype=torch.int64) * SLOTS).to(self.dev)
         self.stream_off = (torch.arange(n_cameras + 1, dtype=torch.int64) * frames_per_camera).to(self.dev)
         self.clip_w = torch.full((n_cameras,), float(width), dtype=torch.float64, device=self.dev)
         self.clip_h = torch.full((n_cameras,), float(height), dtype=torch.float64, device=self.dev)
-        self.params, self._keep = make_params(max_age, min_hits, list(score_threshold), list(iou_threshold))
-        self.lib = _lib.lib()
-        ws = int(self.lib.wt_track_streams_workspace(C.c_int64(n), C.c_int64(self.n_frames), C.c_int32(n_cameras),
-                                                     C.c_int64(SLOTS), C.byref(self.params)))
-        self.ws = torch.empty(ws, dtype=torch.uint8, device=self.dev)
-        self.out_frame = torch.empty(n + 1, dtype=torch.int64, device=self.dev)
-        self.out_cat = torch.empty(n + 1, dtype=torch.int32, device=self.dev)
-        self.out_bbox = torch.empty((n + 1, 4), dtype=torch.float64, device=self.dev)
-        self.out_score = torch.empty(n + 1, dtype=torch.float64, device=self.dev)
-        self.out_id = torch.empty(n + 1, dtype=torch.int64, device=self.dev)
-        self.counts = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self.track_params = dict(iou_threshold=list(iou_threshold), score_threshold=list(score_threshold),
+                                 max_age=max_age, min_hits=min_hits)
+        self.tracker = StreamingTracker(n_cameras, SLOTS, self.n_frames, n, list(iou_threshold), max_age, min_hits,
+                                        list(score_threshold), device=self.dev)
+        self.track_stream = torch.cuda.Stream(device=self.dev)
+        self._prev_done = None
+        self.chunk = 0                 # chunks of the current segment processed so far
+        self.time = 0                  # frame time index into self.frames
+        self.segments_done = 0
         self.n_dets_last = 0
 
-    def _bind(self, i):
-        self._cur = i
-        for k, v in self._slots[i].items():
-            setattr(self, k, v)
+    @property
+    def counts(self):
+        """(rows, births) of the most recent chunk (device int64[2])."""
+        return self.chunk_counts[max(self.chunk - 1, 0)]
 
-    def detect_frame(self, f):
-        """Frame f (camera-major order) -> wire-format detections written into slots [f*100, f*100+100)."""
+    def detect_frame(self, c, cam, j):
+        """Frame j of camera cam of chunk c -> wire-format detections in that frame's 100 slots."""
         # decoded uint8 HWC RGB frame -> fused pre-processing kernel (ToTensor(scaling=False) + BGR + normalise + pad)
-        (boxes, scores, classes), = self.model.predict_device(self.frames[f:f + 1], self.tta_scale, self.tta_hflip)
+        img = self.frames[(self.time + j) % self.n_times, cam].unsqueeze(0)
+        (boxes, scores, classes), = self.model.predict_device(img, self.tta_scale, self.tta_hflip)
         ho, wo = self.model.last_input_size
         if self.tta_hflip:                                                      # HFlipTTA.post_process: cx <- 1 - cx
             boxes = torch.stack((wo - boxes[:, 2], boxes[:, 1], wo - boxes[:, 0], boxes[:, 3]), dim=1)
         xywh, score, cat = detections_to_wire(boxes, scores, classes, wo, ho, self.w, self.h)
         k = xywh.shape[0]
-        a = f * SLOTS
-        self.category[a:a + SLOTS] = 0                                          # unused slots: category 0 = ignored
-        self.x[a:a + k] = xywh[:, 0]; self.y[a:a + k] = xywh[:, 1]
-        self.wd[a:a + k] = xywh[:, 2]; self.ht[a:a + k] = xywh[:, 3]
-        self.score[a:a + k] = score
-        self.category[a:a + k] = cat
+        a = (cam * self.fpc + j) * SLOTS
+        self.category[c, a:a + SLOTS] = 0                                       # unused slots: category 0 = ignored
+        self.x[c, a:a + k] = xywh[:, 0]; self.y[c, a:a + k] = xywh[:, 1]
+        self.wd[c, a:a + k] = xywh[:, 2]; self.ht[c, a:a + k] = xywh[:, 3]
+        self.score[c, a:a + k] = score
+        self.category[c, a:a + k] = cat
         return k
 
-    def track(self):
-        p = lambda t: C.c_void_p(t.data_ptr())
-        n = self.n_frames * SLOTS
-        rc = self.lib.wt_track_streams_dev(
-            C.c_int64(n), p(self.x), p(self.y), p(self.wd), p(self.ht), p(self.score), p(self.category),
-            C.c_int64(self.n_frames), p(self.frame_off), C.c_int32(self.nc), p(self.stream_off), p(self.clip_w),
-            p(self.clip_h), C.c_int64(SLOTS), C.byref(self.params), C.c_int64(0), p(self.out_frame), p(self.out_cat),
-            p(self.out_bbox), p(self.out_score), p(self.out_id), p(self.counts), C.c_void_p(self.counts.data_ptr() + 8),
-            p(self.ws), C.c_size_t(self.ws.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        _lib.check(rc, 'wt_track_streams_dev')
+    def track(self, c):
+        self.tracker.feed(self.x[c], self.y[c], self.wd[c], self.ht[c], self.score[c], self.category[c], self.frame_off,
+                          self.stream_off, self.clip_w, self.clip_h, self.out_frame[c], self.out_cat[c], self.out_bbox[c],
+                          self.out_score[c], self.out_id[c], self.chunk_counts[c])
 
     def step(self, with_tracking=True):
+        main = torch.cuda.current_stream()
+        if self.chunk == self.max_chunks:                        # segment complete: fresh trackers, slots reused
+            if with_tracking:
+                with torch.cuda.stream(self.track_stream):
+                    self.tracker.reset()
+            self.chunk = 0
+            self.segments_done += 1
+        c = self.chunk
+        if self._prev_done is not None:
+            # slots of chunk c may still be read by a track() of the previous segment: it was queued before the most
+            # recent one on the same in-order stream, so waiting for that one covers it
+            main.wait_event(self._prev_done)
         total = 0
-        for f in range(self.n_frames):
-            total += self.detect_frame(f)
+        for cam in range(self.nc):
+            for j in range(self.fpc):
+                total += self.detect_frame(c, cam, j)
         if with_tracking:
-            main = torch.cuda.current_stream()
             filled = torch.cuda.Event()
             filled.record(main)
             with torch.cuda.stream(self.track_stream):
                 self.track_stream.wait_event(filled)             # slots of this chunk are complete
-                self.track()                                     # reads the slot set bound during detection
-                self._track_done = torch.cuda.Event()
-                self._track_done.record(self.track_stream)
-            self._bind(1 - self._cur)                            # the next chunk's detections go to the other set
-            # the set being re-bound was consumed by the track() of the previous step on the same (in-order) stream,
-            # i.e. before the track() just queued; the detector may only overwrite it after that one has finished
-            main.wait_event(self._prev_done) if getattr(self, '_prev_done', None) is not None else None
-            self._prev_done = self._track_done
+                self.track(c)                                    # SORT of chunk c runs under the detector pass of chunk c + 1
+                self._prev_done = torch.cuda.Event()
+                self._prev_done.record(self.track_stream)
+        self.chunk += 1
+        self.time = (self.time + self.fpc) % self.n_times
         self.n_dets_last = total
         return total
+
+    def history(self):
+        """Synchronise and return what the trackers of the CURRENT segment consumed and produced so far:
+        (packed, rows) - `packed` is the pack_streams() layout of the detections (streams = cameras, frames of all chunks
+        in order, empty slots removed), `rows` the tracker output in the reference's order (stream-major) with the
+        reference's global ids (wt_track_global_ids_dev), frame = index into packed's frames."""
+        torch.cuda.synchronize()
+        nch, F, nc = self.chunk, self.fpc, self.nc
+        cat = self.category[:nch].cpu().numpy().reshape(nch, nc, F, SLOTS)
+        arr = {k: getattr(self, a)[:nch].cpu().numpy().reshape(nch, nc, F, SLOTS)
+               for k, a in (('x', 'x'), ('y', 'y'), ('w', 'wd'), ('h', 'ht'), ('score', 'score'))}
+        cols = {k: [] for k in ('x', 'y', 'w', 'h', 'score', 'category')}
+        frame_off, stream_off = [0], [0]
+        n = 0
+        for s in range(nc):
+            for c in range(nch):
+                for j in range(F):
+                    m = cat[c, s, j] != 0
+                    for k in arr:
+                        cols[k].append(arr[k][c, s, j][m])
+                    cols['category'].append(cat[c, s, j][m])
+                    n += int(m.sum())
+                    frame_off.append(n)
+            stream_off.append(len(frame_off) - 1)
+        packed = {k: (np.concatenate(v) if v else np.zeros(0)) for k, v in cols.items()}
+        packed['category'] = packed['category'].astype(np.int32)
+        packed.update(frame_det_offsets=np.asarray(frame_off, np.int64), stream_frame_offsets=np.asarray(stream_off, np.int64),
+                      clip_w=self.clip_w.cpu().numpy(), clip_h=self.clip_h.cpu().numpy())
+        counts = self.chunk_counts[:nch].cpu().numpy()
+        if (counts[:, 0] < 0).any():
+            raise _lib.WaymoTrackError('SORT kernel status %d' % -int(counts[:, 0].min()))
+        fr, ct, bb, sc, lid, st = [], [], [], [], [], []
+        for c in range(nch):
+            k = int(counts[c, 0])
+            f = self.out_frame[c, :k]
+            s = torch.div(f, F, rounding_mode='floor')
+            fr.append(s * (nch * F) + c * F + (f - s * F)); st.append(s)
+            ct.append(self.out_cat[c, :k]); bb.append(self.out_bbox[c, :k]); sc.append(self.out_score[c, :k])
+            lid.append(self.out_id[c, :k])
+        fr, st, ct, bb, sc, lid = [torch.cat(v) for v in (fr, st, ct, bb, sc, lid)]
+        gid = self.tracker.global_ids(st, lid, 0)
+        order = torch.sort(st, stable=True)[1]                   # chunk-major -> stream-major (utils.py output order)
+        rows = dict(frame=fr[order].cpu().numpy(), category=ct[order].cpu().numpy(), bbox=bb[order].cpu().numpy(),
+                    score=sc[order].cpu().numpy(), object_id=gid[order].cpu().numpy())
+        return packed, rows, int(counts[:, 1].sum())
+
+
+def check_against(pipe, track_streams):
+    """Replay the current segment's detections through `track_streams` (the CPU oracle's entry point, injected by the
+    caller: tests / bench.py) and compare with what the GPU trackers produced.  Returns a small report dict."""
+    packed, rows, births = pipe.history()
+    p = pipe.track_params
+    ref = track_streams(packed, p['max_age'], p['min_hits'], p['score_threshold'], p['iou_threshold'])
+    ok = (births == ref['n_births'] and np.array_equal(rows['object_id'], ref['object_id'])
+          and np.array_equal(rows['frame'], ref['frame']) and np.array_equal(rows['category'], ref['category'])
+          and np.array_equal(rows['bbox'], ref['bbox']) and np.allclose(rows['score'], ref['score'], rtol=4e-16, atol=0))
+    return dict(ok=bool(ok), chunks=pipe.chunk, frames=int(packed['frame_det_offsets'].size - 1), dets=int(packed['x'].size),
+                rows=int(len(rows['frame'])), rows_ref=int(len(ref['frame'])), births=births, births_ref=int(ref['n_births']))
 
 
 def _pmc_traffic(tag):
@@ -158,7 +240,8 @@ def run(args, world, rank, timed_steps):
 
     dt, ev_ms = timed_steps(world, step, steps, warmup)
     log, ops.EVENT_LOG = ops.EVENT_LOG or [], None
-    n_out, births = [int(v) for v in pipe.counts.cpu().tolist()]
+    torch.cuda.synchronize()
+    n_out, births = [int(v) for v in pipe.counts.cpu().tolist()] if track else (0, 0)
     frames = pipe.n_frames
     # roofline of the dominant hand-written kernel: the deformable-conv implicit GEMM (47 launches per frame);
     # achieved = algorithmic flops per launch / mean launch duration of the most frequent shape (res4, 36 of 47)
@@ -182,7 +265,7 @@ def run(args, world, rank, timed_steps):
                workload='Cascade R-CNN X152-32x8d-FPN dconv (random-init, fp32, batch 1%s) on synthetic 1920x1280x3 frames'
                         ' -> top-100 detections/frame -> %s; %d cameras x %d frames per step per GPU'
                         % (', --tta ' + args.tta if getattr(args, 'tta', '') else '',
-                           'SORT (max_age 2, min_hits 0, all boxes tracked)' if track else 'no tracking', 5, fps),
+                           'SORT (max_age 2, min_hits 0, all boxes tracked; trackers resident for the whole segment)' if track else 'no tracking', 5, fps),
                roofline=roofline,
                extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births))
     res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters

@@ -20,13 +20,26 @@ namespace {
 constexpr int kLdsCostFloats = 8192;          // 32 KiB of cost matrix in LDS per wave
 constexpr size_t kLdsMunkresMax = 120 * 1024;   // stars / primes / zero bitmaps (dynamic LDS, raised limit)  // stars/primes/covers
 
-struct Workspace {                       // device pointers carved from one block
+// Persistent part of a set of trackers: survives between the chunks of the streaming entry points
+// (wt_track_state_* / wt_track_chunk_dev); the one-shot entry point carves it from its workspace.
+struct State {
     // per tracker
-    double* kx; double* kP; double* pbox;
-    long long* gid;
-    int *tsu, *streak, *bframe, *bk, *order, *freel, *trk_match, *det_match, *new_list, *det_idx;
+    double* kx; double* kP;
+    long long* gid;                      // per track slot: birth ordinal inside its stream once resolved (streaming form)
+    int *tsu, *streak, *bframe, *bk, *order, *freel;
+    int* hdr;                            // [n_trackers][4] TrackerState between chunks
+    long long* first_key;                // per tracker: (stream frame number << 32 | det position) of creation, or -1
+    // per stream
+    long long* s_frames;                 // frames consumed so far
+    long long* s_births;                 // track ids consumed so far
+    size_t bytes;
+};
+
+struct Workspace {                       // device pointers carved from one block (transient: one call)
+    // per tracker
+    double* pbox;
+    int *trk_match, *det_match, *new_list, *det_idx;
     float* cost_g;
-    long long* first_key;                // per tracker: (frame << 32 | det position) of creation, or -1
     // per (frame, class)
     int* cnt;                            // emitted rows
     int* births;                         // births
@@ -34,6 +47,7 @@ struct Workspace {                       // device pointers carved from one bloc
     // per intermediate slot
     double* irow;                        // [5][n_dets]: x1, y1, w, h, score
     int *ifr, *isc, *ij, *ibf, *ibk;
+    long long* igid;                     // resolved birth ordinal of the emitting track (streaming form, ibf < 0)
     // ranked
     int* rank;                           // [n_streams * C]: class rank inside its stream or -1
     long long* rcnt;                     // [n_frames * C] ranked row counts -> exclusive scan
@@ -44,27 +58,38 @@ struct Workspace {                       // device pointers carved from one bloc
     size_t bytes;
 };
 
+State carve_state(void* base, int32_t n_streams, int C, int cap) {
+    wt::Carver cv(base);
+    State st;
+    const size_t nt = (size_t)n_streams * (size_t)C;
+    st.kx = cv.take<double>(nt * 7 * cap);
+    st.kP = cv.take<double>(nt * 49 * cap);
+    st.gid = cv.take<long long>(nt * cap);
+    st.tsu = cv.take<int>(nt * cap);
+    st.streak = cv.take<int>(nt * cap);
+    st.bframe = cv.take<int>(nt * cap);
+    st.bk = cv.take<int>(nt * cap);
+    st.order = cv.take<int>(nt * cap);
+    st.freel = cv.take<int>(nt * cap);
+    st.hdr = cv.take<int>(nt * 4);
+    st.first_key = cv.take<long long>(nt);
+    st.s_frames = cv.take<long long>((size_t)n_streams);
+    st.s_births = cv.take<long long>((size_t)n_streams);
+    st.bytes = cv.off;
+    return st;
+}
+
 Workspace carve_ws(void* base, int64_t n_dets, int64_t n_frames, int32_t n_streams, int C, int cap, int capN,
                    bool need_cost_g) {
     wt::Carver cv(base);
     Workspace w;
     const size_t nt = (size_t)n_streams * (size_t)C;
-    w.kx = cv.take<double>(nt * 7 * cap);
-    w.kP = cv.take<double>(nt * 49 * cap);
     w.pbox = cv.take<double>(nt * 4 * cap);
-    w.gid = cv.take<long long>(nt * cap);
-    w.tsu = cv.take<int>(nt * cap);
-    w.streak = cv.take<int>(nt * cap);
-    w.bframe = cv.take<int>(nt * cap);
-    w.bk = cv.take<int>(nt * cap);
-    w.order = cv.take<int>(nt * cap);
-    w.freel = cv.take<int>(nt * cap);
     w.trk_match = cv.take<int>(nt * cap);
     w.det_match = cv.take<int>(nt * capN);
     w.new_list = cv.take<int>(nt * capN);
     w.det_idx = cv.take<int>(nt * capN);
     w.cost_g = cv.take<float>(need_cost_g ? nt * (size_t)capN * (cap | 1) : 1);
-    w.first_key = cv.take<long long>(nt);
     w.cnt = cv.take<int>((size_t)n_frames * C);
     w.births = cv.take<int>((size_t)n_frames * C);
     w.ibase = cv.take<long long>((size_t)n_frames * C);
@@ -74,6 +99,7 @@ Workspace carve_ws(void* base, int64_t n_dets, int64_t n_frames, int32_t n_strea
     w.ij = cv.take<int>((size_t)n_dets + 1);
     w.ibf = cv.take<int>((size_t)n_dets + 1);
     w.ibk = cv.take<int>((size_t)n_dets + 1);
+    w.igid = cv.take<long long>((size_t)n_dets + 1);
     w.rank = cv.take<int>(nt);
     w.rcnt = cv.take<long long>((size_t)n_frames * C + 1);
     w.rbirths = cv.take<long long>((size_t)n_frames * C + 1);
@@ -85,18 +111,19 @@ Workspace carve_ws(void* base, int64_t n_dets, int64_t n_frames, int32_t n_strea
     return w;
 }
 
-__device__ __forceinline__ TrackerMem tracker_mem(const Workspace& w, size_t tk, int cap, int capN, bool cost_g) {
+__device__ __forceinline__ TrackerMem tracker_mem(const State& st, const Workspace& w, size_t tk, int cap, int capN,
+                                                  bool cost_g) {
     TrackerMem M;
-    M.kx = w.kx + tk * 7 * cap;
-    M.kP = w.kP + tk * 49 * cap;
+    M.kx = st.kx + tk * 7 * cap;
+    M.kP = st.kP + tk * 49 * cap;
     M.pbox = w.pbox + tk * 4 * cap;
-    M.gid = w.gid + tk * cap;
-    M.tsu = w.tsu + tk * cap;
-    M.streak = w.streak + tk * cap;
-    M.bframe = w.bframe + tk * cap;
-    M.bk = w.bk + tk * cap;
-    M.order = w.order + tk * cap;
-    M.freel = w.freel + tk * cap;
+    M.gid = st.gid + tk * cap;
+    M.tsu = st.tsu + tk * cap;
+    M.streak = st.streak + tk * cap;
+    M.bframe = st.bframe + tk * cap;
+    M.bk = st.bk + tk * cap;
+    M.order = st.order + tk * cap;
+    M.freel = st.freel + tk * cap;
     M.trk_match = w.trk_match + tk * cap;
     M.det_match = w.det_match + tk * capN;
     M.new_list = w.new_list + tk * capN;
@@ -126,6 +153,7 @@ struct StreamEmit {       // utils.py:38-58 clip / drop / confidence clip, into 
     double cw, ch;
     double* irow;
     int *ifr, *isc, *ij, *ibf, *ibk;
+    long long* igid;
     long long n_slots, base;
     int f, sc;
     __device__ __forceinline__ static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -138,8 +166,9 @@ struct StreamEmit {       // utils.py:38-58 clip / drop / confidence clip, into 
         }
         return true;
     }
-    __device__ __forceinline__ void write(int j, const double b[4], double conf, long long, int bframe, int bk) const {
+    __device__ __forceinline__ void write(int j, const double b[4], double conf, long long gid, int bframe, int bk) const {
         const long long p = base + j;
+        igid[p] = gid;
         irow[p] = b[0];
         irow[n_slots + p] = b[1];
         irow[2 * n_slots + p] = b[2] - b[0];
@@ -154,7 +183,7 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
     const double* __restrict__ h, const double* __restrict__ score, const int32_t* __restrict__ category,
     const int64_t* __restrict__ frame_det_offsets, const int64_t* __restrict__ stream_frame_offsets,
     const double* __restrict__ clip_w, const double* __restrict__ clip_h, int C, int max_age, int min_hits,
-    int cap, int capN, int lds_cost_cap, bool have_cost_g, long long n_slots, Workspace ws) {
+    int cap, int capN, int lds_cost_cap, bool have_cost_g, long long n_slots, Workspace ws, State st, int resume) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const unsigned long long lt = lanemask_lt();
@@ -163,15 +192,24 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
     const int c = (int)(tk % C) + 1;
     float* lds_cost = reinterpret_cast<float*>(smem);
     MunkresMem L = munkres_mem(smem + (((size_t)lds_cost_cap * sizeof(float) + 15) / 16) * 16, capN, cap);
-    TrackerMem M = tracker_mem(ws, tk, cap, capN, have_cost_g);
+    TrackerMem M = tracker_mem(st, ws, tk, cap, capN, have_cost_g);
     int* det_idx = ws.det_idx + tk * capN;
-    for (int i = lane; i < cap; i += kWave) M.freel[i] = cap - 1 - i;
     TrackerState S = {0, cap, 0, 0};
+    bool created = false;
+    long long first_key = -1;
+    long long frames_before = 0;                 // frames of this stream consumed by earlier chunks
+    if (resume) {                                // streaming form: continue where the previous chunk stopped
+        S.n_tracks = st.hdr[tk * 4 + 0]; S.n_free = st.hdr[tk * 4 + 1];
+        S.frame_count = st.hdr[tk * 4 + 2]; S.next_local = st.hdr[tk * 4 + 3];
+        first_key = st.first_key[tk];
+        created = first_key >= 0;
+        frames_before = st.s_frames[s];
+    } else {
+        for (int i = lane; i < cap; i += kWave) M.freel[i] = cap - 1 - i;
+    }
     __syncthreads();
     const double thr_iou = ws.thr_iou[c - 1];
     const double cw = clip_w ? clip_w[s] : 0.0, ch = clip_h ? clip_h[s] : 0.0;
-    bool created = false;
-    long long first_key = -1;
     const long long f0 = stream_frame_offsets[s], f1 = stream_frame_offsets[s + 1];
     for (long long f = f0; f < f1; ++f) {
         const long long d0 = frame_det_offsets[f], d1 = frame_det_offsets[f + 1];
@@ -201,11 +239,11 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
         if (!created) {
             if (N == 0) continue;
             created = true;
-            first_key = ((f - f0) << 32) | (long long)first_pos;
+            first_key = ((f - f0 + frames_before) << 32) | (long long)first_pos;
         }
         __syncthreads();
         StreamDets dets = {x, y, w, h, det_idx, d0};
-        StreamEmit emit = {cw, ch, ws.irow, ws.ifr, ws.isc, ws.ij, ws.ibf, ws.ibk, n_slots, d0 + lower, (int)f, (int)tk};
+        StreamEmit emit = {cw, ch, ws.irow, ws.ifr, ws.isc, ws.ij, ws.ibf, ws.ibk, ws.igid, n_slots, d0 + lower, (int)f, (int)tk};
         int nb = 0, nr = 0;
         int rc = overflow ? WT_ERR_CAPACITY
                           : tracker_step(M, S, L, lds_cost, lds_cost_cap, dets, N, thr_iou, max_age, min_hits, (int)f,
@@ -216,20 +254,24 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
         }
         if (lane == 0) { ws.cnt[f * C + c - 1] = nr; ws.births[f * C + c - 1] = nb; }
     }
-    if (lane == 0) ws.first_key[tk] = created ? first_key : -1;
+    if (lane == 0) {
+        st.first_key[tk] = created ? first_key : -1;
+        st.hdr[tk * 4 + 0] = S.n_tracks; st.hdr[tk * 4 + 1] = S.n_free;
+        st.hdr[tk * 4 + 2] = S.frame_count; st.hdr[tk * 4 + 3] = S.next_local;
+    }
 }
 
 // class rank inside its stream = order of first appearance (dict insertion order, tracker_sort.py:32-33,41)
-__global__ void rank_classes_kernel(int n_streams, int C, Workspace ws) {
+__global__ void rank_classes_kernel(int n_streams, int C, Workspace ws, State st) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
     for (int c = 0; c < C; ++c) {
-        const long long k = ws.first_key[(size_t)s * C + c];
+        const long long k = st.first_key[(size_t)s * C + c];
         int r = -1;
         if (k >= 0) {
             r = 0;
             for (int o = 0; o < C; ++o) {
-                const long long ko = ws.first_key[(size_t)s * C + o];
+                const long long ko = st.first_key[(size_t)s * C + o];
                 if (o != c && ko >= 0 && ko < k) ++r;
             }
         }
@@ -282,7 +324,15 @@ __global__ __launch_bounds__(1024) void scan2_kernel(long long n, long long* a, 
     if (t == 1023) { totals[0] = sa[1023]; totals[1] = sb[1023]; }
 }
 
-__global__ void finalize_kernel(long long n_slots, int C, long long id_base, Workspace ws,
+// births of stream s in this call that precede (frame f, class rank r): exclusive scan value minus the stream's base
+__device__ __forceinline__ long long stream_birth_rank(const Workspace& ws, const int64_t* sfo, int s, long long f, int r, int C) {
+    return ws.rbirths[f * C + r] - ws.rbirths[(long long)sfo[s] * C];
+}
+
+// local_ids (streaming form): out_object_id = 0-based ordinal of the track's birth inside ITS stream, counted over all
+// chunks so far (the reference's id minus one minus the births of the streams in front of it, sort.py:86,140-141)
+__global__ void finalize_kernel(long long n_slots, int C, long long id_base, Workspace ws, State st, int local_ids,
+                                const int64_t* __restrict__ stream_frame_offsets,
                                 int64_t* __restrict__ out_frame, int32_t* __restrict__ out_category,
                                 double* __restrict__ out_bbox4, double* __restrict__ out_score,
                                 int64_t* __restrict__ out_object_id) {
@@ -298,8 +348,84 @@ __global__ void finalize_kernel(long long n_slots, int C, long long id_base, Wor
 #pragma unroll
     for (int q = 0; q < 4; ++q) out_bbox4[4 * dst + q] = ws.irow[q * n_slots + p];
     out_score[dst] = ws.irow[4 * n_slots + p];
-    // sort.py:141 id = count++ ; :288 emits id + 1
-    out_object_id[dst] = id_base + ws.rbirths[(long long)ws.ibf[p] * C + r] + ws.ibk[p] + 1;
+    const int bf = ws.ibf[p];
+    if (!local_ids) {
+        // sort.py:141 id = count++ ; :288 emits id + 1
+        out_object_id[dst] = id_base + ws.rbirths[(long long)bf * C + r] + ws.ibk[p] + 1;
+    } else if (bf < 0) {
+        out_object_id[dst] = ws.igid[p];                          // born in an earlier chunk
+    } else {
+        const int s = sc / C;
+        out_object_id[dst] = st.s_births[s] + stream_birth_rank(ws, stream_frame_offsets, s, bf, r, C) + ws.ibk[p];
+    }
+}
+
+// streaming form, end of a chunk: tracks born in this chunk get their stream-local birth ordinal (their (frame, rank)
+// coordinates are only meaningful inside the chunk)
+__global__ __launch_bounds__(kWave) void resolve_births_kernel(int C, int cap, Workspace ws, State st,
+                                                               const int64_t* __restrict__ stream_frame_offsets) {
+    const size_t tk = blockIdx.x;
+    const int s = (int)(tk / C);
+    const int r = ws.rank[tk];
+    const int n = st.hdr[tk * 4 + 0];
+    for (int i = threadIdx.x; i < n; i += kWave) {
+        const int slot = st.order[tk * cap + i];
+        const int bf = st.bframe[tk * cap + slot];
+        if (bf >= 0) {
+            st.gid[tk * cap + slot] = st.s_births[s] + stream_birth_rank(ws, stream_frame_offsets, s, bf, r, C) + st.bk[tk * cap + slot];
+            st.bframe[tk * cap + slot] = -1;
+        }
+    }
+}
+
+__global__ void advance_streams_kernel(int n_streams, int C, long long n_frames, Workspace ws, State st,
+                                       const int64_t* __restrict__ stream_frame_offsets) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const long long f0 = stream_frame_offsets[s], f1 = stream_frame_offsets[s + 1];
+    if (f1 <= f0) return;
+    const long long end = (f1 < n_frames) ? ws.rbirths[f1 * C] : ws.totals[1];
+    st.s_births[s] += end - ws.rbirths[f0 * C];
+    st.s_frames[s] += f1 - f0;
+}
+
+__global__ void state_init_kernel(int n_streams, int C, int cap, State st) {
+    const long long nt = (long long)n_streams * C;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nt * cap) st.freel[i] = cap - 1 - (int)(i % cap);
+    if (i < nt) {
+        st.hdr[i * 4 + 0] = 0; st.hdr[i * 4 + 1] = cap; st.hdr[i * 4 + 2] = 0; st.hdr[i * 4 + 3] = 0;
+        st.first_key[i] = -1;
+    }
+    if (i < n_streams) { st.s_frames[i] = 0; st.s_births[i] = 0; }
+}
+
+// reference ids of rows produced by the streaming form: id = id_base + (births of the streams in front) + ordinal + 1
+__global__ __launch_bounds__(1024) void stream_prefix_kernel(int n_streams, State st, long long* __restrict__ prefix) {
+    __shared__ long long sa[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n_streams + 1023) / 1024;
+    const int lo = t * chunk, hi = (lo + chunk < n_streams) ? lo + chunk : n_streams;
+    long long x = 0;
+    for (int i = lo; i < hi; ++i) x += st.s_births[i];
+    sa[t] = x;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        long long v = 0;
+        if (t >= o) v = sa[t - o];
+        __syncthreads();
+        sa[t] += v;
+        __syncthreads();
+    }
+    long long run = sa[t] - x;
+    for (int i = lo; i < hi; ++i) { prefix[i] = run; run += st.s_births[i]; }
+    if (t == 1023) prefix[n_streams] = sa[1023];
+}
+
+__global__ void global_ids_kernel(long long n, const int32_t* __restrict__ row_stream, const int64_t* __restrict__ local_id,
+                                  const long long* __restrict__ prefix, long long id_base, int64_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = id_base + prefix[row_stream[i]] + local_id[i] + 1;
 }
 
 __global__ void totals_kernel(const long long* totals, const int* err, int64_t* n_out, int64_t* n_births) {
@@ -329,13 +455,67 @@ int pick_caps(int64_t max_frame_dets, const wt_track_params* p, int* cap, int* c
 
 }  // namespace
 
+namespace {
+// one tracking pass over the given frames; `st` holds the trackers (fresh when !resume)
+int run_tracking(int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
+                 const double* score, const int32_t* category, int64_t n_frames, const int64_t* frame_det_offsets,
+                 int32_t n_streams, const int64_t* stream_frame_offsets, const double* clip_w, const double* clip_h,
+                 const wt_track_params* params, int64_t id_base, int64_t* out_frame, int32_t* out_category,
+                 double* out_bbox4, double* out_score, int64_t* out_object_id, int64_t* n_out_dev, int64_t* n_births_dev,
+                 const Workspace& ws, const State& st, int resume, int cap, int capN, int lds_cost, bool cost_g, size_t lds,
+                 hipStream_t stream) {
+    const int C = params->n_classes;
+    WT_HIP(hipMemcpyAsync(ws.thr_score, params->score_threshold, sizeof(double) * C, hipMemcpyHostToDevice, stream));
+    WT_HIP(hipMemcpyAsync(ws.thr_iou, params->iou_threshold, sizeof(double) * C, hipMemcpyHostToDevice, stream));
+    WT_HIP(hipMemsetAsync(ws.err, 0, sizeof(int) * 4, stream));
+    WT_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * (size_t)n_frames * C, stream));
+    WT_HIP(hipMemsetAsync(ws.births, 0, sizeof(int) * (size_t)n_frames * C, stream));
+    WT_HIP(hipMemsetAsync(ws.ifr, 0xFF, sizeof(int) * ((size_t)n_dets + 1), stream));
+    WT_HIP(hipMemsetAsync(ws.rcnt, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
+    WT_HIP(hipMemsetAsync(ws.rbirths, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
+    const unsigned n_trackers = (unsigned)n_streams * (unsigned)C;
+    if (lds > 48 * 1024)
+        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_streams_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(sort_streams_kernel, dim3(n_trackers), dim3(kWave), lds, stream, x, y, w, h, score, category,
+                       frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
+                       (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws, st, resume);
+    WT_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rank_classes_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, (int)n_streams, C, ws, st);
+    const long long ne = (long long)n_frames * C;
+    hipLaunchKernelGGL(gather_ranked_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream,
+                       (long long)n_frames, (int)n_streams, C, stream_frame_offsets, ws);
+    hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(1024), 0, stream, ne, ws.rcnt, ws.rbirths, ws.totals);
+    if (n_dets > 0)
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_dets + 255) / 256)), dim3(256), 0, stream,
+                           (long long)n_dets, C, (long long)id_base, ws, st, resume, stream_frame_offsets, out_frame,
+                           out_category, out_bbox4, out_score, out_object_id);
+    if (resume) {
+        hipLaunchKernelGGL(resolve_births_kernel, dim3(n_trackers), dim3(kWave), 0, stream, C, cap, ws, st,
+                           stream_frame_offsets);
+        hipLaunchKernelGGL(advance_streams_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, (int)n_streams, C,
+                           (long long)n_frames, ws, st, stream_frame_offsets);
+    }
+    hipLaunchKernelGGL(totals_kernel, dim3(1), dim3(1), 0, stream, (const long long*)ws.totals, ws.err, n_out_dev,
+                       n_births_dev);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+inline char* align256(void* p) {
+    const uintptr_t mis = (uintptr_t)p & 255;
+    return (char*)p + (mis ? 256 - mis : 0);
+}
+}  // namespace
+
 extern "C" {
 
 size_t wt_track_streams_workspace(int64_t n_dets, int64_t n_frames, int32_t n_streams, int64_t max_frame_dets,
                                   const wt_track_params* params) {
     int cap, capN, lds_cost; bool cost_g; size_t lds;
     if (pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds) != WT_OK) return 0;
-    return carve_ws(nullptr, n_dets, n_frames, n_streams, params->n_classes, cap, capN, cost_g).bytes + 256;
+    return carve_ws(nullptr, n_dets, n_frames, n_streams, params->n_classes, cap, capN, cost_g).bytes +
+           carve_state(nullptr, n_streams, params->n_classes, cap).bytes + 256;
 }
 
 int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
@@ -357,40 +537,104 @@ int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const
         WT_HIP(hipMemsetAsync(n_births_dev, 0, sizeof(int64_t), stream));
         return WT_OK;
     }
-    const uintptr_t mis = (uintptr_t)workspace & 255;
-    char* base = (char*)workspace + (mis ? 256 - mis : 0);
+    char* base = align256(workspace);
     Workspace ws = carve_ws(base, n_dets, n_frames, n_streams, C, cap, capN, cost_g);
+    State st = carve_state(base + ws.bytes, n_streams, C, cap);
+    if (!workspace || workspace_bytes < ws.bytes + st.bytes + 256) {
+        wt::set_error("tracking workspace too small: need %zu bytes, have %zu", ws.bytes + st.bytes + 256, workspace_bytes);
+        return WT_ERR_CAPACITY;
+    }
+    return run_tracking(n_dets, x, y, w, h, score, category, n_frames, frame_det_offsets, n_streams, stream_frame_offsets,
+                        clip_w, clip_h, params, id_base, out_frame, out_category, out_bbox4, out_score, out_object_id,
+                        n_out_dev, n_births_dev, ws, st, 0, cap, capN, lds_cost, cost_g, lds, stream);
+}
+
+/* ---- streaming form: the trackers persist in `state` between chunks of frames ---- */
+size_t wt_track_state_bytes(int32_t n_streams, int64_t max_frame_dets, const wt_track_params* params) {
+    int cap, capN, lds_cost; bool cost_g; size_t lds;
+    if (n_streams <= 0 || pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds) != WT_OK) return 0;
+    return carve_state(nullptr, n_streams, params->n_classes, cap).bytes + 256;
+}
+
+int wt_track_state_init_dev(void* state, size_t state_bytes, int32_t n_streams, int64_t max_frame_dets,
+                            const wt_track_params* params, void* stream_) {
+    WT_TRY(wt::ensure_device());
+    int cap, capN, lds_cost; bool cost_g; size_t lds;
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    if (n_streams <= 0) { wt::set_error("n_streams must be positive"); return WT_ERR_INVALID; }
+    const int C = params->n_classes;
+    State st = carve_state(align256(state), n_streams, C, cap);
+    if (!state || state_bytes < st.bytes + 256) {
+        wt::set_error("tracker state too small: need %zu bytes, have %zu", st.bytes + 256, state_bytes);
+        return WT_ERR_CAPACITY;
+    }
+    const long long items = (long long)n_streams * C * cap;
+    hipLaunchKernelGGL(state_init_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                       (int)n_streams, C, cap, st);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+size_t wt_track_chunk_workspace(int64_t n_dets, int64_t n_frames, int32_t n_streams, int64_t max_frame_dets,
+                                const wt_track_params* params) {
+    int cap, capN, lds_cost; bool cost_g; size_t lds;
+    if (pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds) != WT_OK) return 0;
+    return carve_ws(nullptr, n_dets, n_frames, n_streams, params->n_classes, cap, capN, cost_g).bytes + 256;
+}
+
+int wt_track_chunk_dev(void* state, size_t state_bytes,
+                       int64_t n_dets, const double* x, const double* y, const double* w, const double* h,
+                       const double* score, const int32_t* category,
+                       int64_t n_frames, const int64_t* frame_det_offsets,
+                       int32_t n_streams, const int64_t* stream_frame_offsets,
+                       const double* clip_w, const double* clip_h, int64_t max_frame_dets,
+                       const wt_track_params* params,
+                       int64_t* out_frame, int32_t* out_category, double* out_bbox4, double* out_score,
+                       int64_t* out_local_id, int64_t* n_out_dev, int64_t* n_births_dev,
+                       void* workspace, size_t workspace_bytes, void* stream_) {
+    WT_TRY(wt::ensure_device());
+    hipStream_t stream = (hipStream_t)stream_;
+    int cap, capN, lds_cost; bool cost_g; size_t lds;
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    const int C = params->n_classes;
+    if (n_streams <= 0) { wt::set_error("n_streams must be positive"); return WT_ERR_INVALID; }
+    if (n_frames <= 0) {
+        WT_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), stream));
+        WT_HIP(hipMemsetAsync(n_births_dev, 0, sizeof(int64_t), stream));
+        return WT_OK;
+    }
+    State st = carve_state(align256(state), n_streams, C, cap);
+    if (!state || state_bytes < st.bytes + 256) {
+        wt::set_error("tracker state too small: need %zu bytes, have %zu", st.bytes + 256, state_bytes);
+        return WT_ERR_CAPACITY;
+    }
+    Workspace ws = carve_ws(align256(workspace), n_dets, n_frames, n_streams, C, cap, capN, cost_g);
     if (!workspace || workspace_bytes < ws.bytes + 256) {
         wt::set_error("tracking workspace too small: need %zu bytes, have %zu", ws.bytes + 256, workspace_bytes);
         return WT_ERR_CAPACITY;
     }
-    WT_HIP(hipMemcpyAsync(ws.thr_score, params->score_threshold, sizeof(double) * C, hipMemcpyHostToDevice, stream));
-    WT_HIP(hipMemcpyAsync(ws.thr_iou, params->iou_threshold, sizeof(double) * C, hipMemcpyHostToDevice, stream));
-    WT_HIP(hipMemsetAsync(ws.err, 0, sizeof(int) * 4, stream));
-    WT_HIP(hipMemsetAsync(ws.cnt, 0, sizeof(int) * (size_t)n_frames * C, stream));
-    WT_HIP(hipMemsetAsync(ws.births, 0, sizeof(int) * (size_t)n_frames * C, stream));
-    WT_HIP(hipMemsetAsync(ws.ifr, 0xFF, sizeof(int) * ((size_t)n_dets + 1), stream));
-    WT_HIP(hipMemsetAsync(ws.rcnt, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
-    WT_HIP(hipMemsetAsync(ws.rbirths, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
-    const unsigned n_trackers = (unsigned)n_streams * (unsigned)C;
-    if (lds > 48 * 1024)
-        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_streams_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_streams_kernel, dim3(n_trackers), dim3(kWave), lds, stream, x, y, w, h, score, category,
-                       frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
-                       (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws);
-    WT_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rank_classes_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, (int)n_streams, C, ws);
-    const long long ne = (long long)n_frames * C;
-    hipLaunchKernelGGL(gather_ranked_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, stream,
-                       (long long)n_frames, (int)n_streams, C, stream_frame_offsets, ws);
-    hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(1024), 0, stream, ne, ws.rcnt, ws.rbirths, ws.totals);
-    if (n_dets > 0)
-        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_dets + 255) / 256)), dim3(256), 0, stream,
-                           (long long)n_dets, C, (long long)id_base, ws, out_frame, out_category, out_bbox4, out_score,
-                           out_object_id);
-    hipLaunchKernelGGL(totals_kernel, dim3(1), dim3(1), 0, stream, (const long long*)ws.totals, ws.err, n_out_dev,
-                       n_births_dev);
+    return run_tracking(n_dets, x, y, w, h, score, category, n_frames, frame_det_offsets, n_streams, stream_frame_offsets,
+                        clip_w, clip_h, params, 0, out_frame, out_category, out_bbox4, out_score, out_local_id,
+                        n_out_dev, n_births_dev, ws, st, 1, cap, capN, lds_cost, cost_g, lds, stream);
+}
+
+int wt_track_global_ids_dev(const void* state, size_t state_bytes, int32_t n_streams, int64_t max_frame_dets,
+                            const wt_track_params* params, int64_t n_rows, const int32_t* row_stream,
+                            const int64_t* local_id, int64_t id_base, int64_t* out_object_id, int64_t* stream_birth_prefix,
+                            void* stream_) {
+    WT_TRY(wt::ensure_device());
+    hipStream_t stream = (hipStream_t)stream_;
+    int cap, capN, lds_cost; bool cost_g; size_t lds;
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    if (n_streams <= 0 || !stream_birth_prefix) { wt::set_error("bad arguments"); return WT_ERR_INVALID; }
+    State st = carve_state(align256(const_cast<void*>(state)), n_streams, params->n_classes, cap);
+    if (!state || state_bytes < st.bytes + 256) { wt::set_error("tracker state too small"); return WT_ERR_CAPACITY; }
+    hipLaunchKernelGGL(stream_prefix_kernel, dim3(1), dim3(1024), 0, stream, (int)n_streams, st,
+                       (long long*)stream_birth_prefix);
+    if (n_rows > 0)
+        hipLaunchKernelGGL(global_ids_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream,
+                           (long long)n_rows, row_stream, local_id, (const long long*)stream_birth_prefix,
+                           (long long)id_base, out_object_id);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

@@ -101,3 +101,62 @@ class DeviceEnsemble(object):
                                              _dp(self.out5), _dp(self.counts), _dp(self.workspace),
                                              C.c_size_t(self.ws_bytes), _stream())
         _lib.check(rc, 'wt_ensemble_groups_dev')
+
+
+class StreamingTracker(object):
+    """wt_track_state_* / wt_track_chunk_dev: trackers that stay resident in HBM while the frames of their streams arrive
+    chunk by chunk (online detect -> track; tracking/utils.py:29-36 keeps one MultiClassTrackerSort per stream alive).
+
+    All chunks of one tracker share `max_frame_dets`; a chunk holds at most `max_chunk_frames` frames / `max_chunk_dets`
+    detection slots.  Nothing here synchronises with the host."""
+
+    def __init__(self, n_streams, max_frame_dets, max_chunk_frames, max_chunk_dets, iou_threshold, max_age, min_hits,
+                 score_threshold=None, device='cuda'):
+        self.lib = _lib.lib()
+        self.dev = torch.device(device)
+        self.n_streams, self.max_frame = int(n_streams), int(max_frame_dets)
+        self.params, self._keep = make_params(max_age, min_hits, score_threshold, iou_threshold)
+        sb = int(self.lib.wt_track_state_bytes(C.c_int32(self.n_streams), C.c_int64(self.max_frame), C.byref(self.params)))
+        wb = int(self.lib.wt_track_chunk_workspace(C.c_int64(max_chunk_dets), C.c_int64(max_chunk_frames),
+                                                   C.c_int32(self.n_streams), C.c_int64(self.max_frame),
+                                                   C.byref(self.params)))
+        if sb == 0 or wb == 0:
+            raise _lib.WaymoTrackError('streaming tracker sizes: ' + (self.lib.wt_last_error() or b'').decode())
+        self.state = torch.empty(sb, dtype=torch.uint8, device=self.dev)
+        self.workspace = torch.empty(wb, dtype=torch.uint8, device=self.dev)
+        self.prefix = torch.zeros(self.n_streams + 1, dtype=torch.int64, device=self.dev)
+        self.max_chunk_frames, self.max_chunk_dets = int(max_chunk_frames), int(max_chunk_dets)
+        self.reset()
+
+    def reset(self):
+        """Fresh trackers for every stream (a new segment starts)."""
+        _lib.check(self.lib.wt_track_state_init_dev(_dp(self.state), C.c_size_t(self.state.numel()),
+                                                    C.c_int32(self.n_streams), C.c_int64(self.max_frame),
+                                                    C.byref(self.params), _stream()), 'wt_track_state_init_dev')
+
+    def feed(self, x, y, w, h, score, category, frame_off, stream_off, clip_w, clip_h, out_frame, out_category, out_bbox,
+             out_score, out_local_id, counts):
+        """Enqueue one chunk on the current stream.  counts: int64[2] device tensor (rows, births of this chunk)."""
+        n = int(x.numel())
+        nf = int(frame_off.numel()) - 1
+        if n > self.max_chunk_dets or nf > self.max_chunk_frames:
+            raise ValueError('chunk exceeds the sizes this tracker was created for')
+        rc = self.lib.wt_track_chunk_dev(
+            _dp(self.state), C.c_size_t(self.state.numel()), C.c_int64(n), _dp(x), _dp(y), _dp(w), _dp(h), _dp(score),
+            _dp(category), C.c_int64(nf), _dp(frame_off), C.c_int32(self.n_streams), _dp(stream_off), _dp(clip_w),
+            _dp(clip_h), C.c_int64(self.max_frame), C.byref(self.params), _dp(out_frame), _dp(out_category), _dp(out_bbox),
+            _dp(out_score), _dp(out_local_id), C.c_void_p(counts.data_ptr()), C.c_void_p(counts.data_ptr() + 8),
+            _dp(self.workspace), C.c_size_t(self.workspace.numel()), _stream())
+        _lib.check(rc, 'wt_track_chunk_dev')
+
+    def global_ids(self, row_stream, local_id, id_base=0):
+        """Reference object ids (sort.py:86,140-141 order) of collected rows, once their streams are complete."""
+        row_stream = row_stream.to(torch.int32).contiguous()
+        local_id = local_id.to(torch.int64).contiguous()
+        out = torch.empty_like(local_id)
+        rc = self.lib.wt_track_global_ids_dev(_dp(self.state), C.c_size_t(self.state.numel()), C.c_int32(self.n_streams),
+                                              C.c_int64(self.max_frame), C.byref(self.params), C.c_int64(local_id.numel()),
+                                              _dp(row_stream), _dp(local_id), C.c_int64(id_base), _dp(out), _dp(self.prefix),
+                                              _stream())
+        _lib.check(rc, 'wt_track_global_ids_dev')
+        return out
