@@ -303,6 +303,32 @@ def test_deform_conv_every_kernel_variant(monkeypatch, variant, C, off_std):
     np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('H,W,batch,off_std', [(19, 27, 1, 0.6), (16, 24, 2, 0.0), (40, 33, 1, 3.0), (8, 8, 1, 1.0), (80, 120, 1, 0.6)])
+def test_deform_conv_pingpong_kernel(monkeypatch, H, W, batch, off_std):
+    """The two-team ping-pong kernel (det_deform_pp.hip; 32 channels per group, stride 1, no mask) against the float64
+    restatement: partial tiles, several images, zero / small / large offsets (per-lane global fallback), odd tile counts
+    per workgroup (dummy item of team 1), fused FrozenBN affine + ReLU."""
+    from oracle import detops_ref as R
+    monkeypatch.setenv('WD_DEFORM_PATCH', 'pp')
+    C = 1024 if H < 80 else 256
+    name = ops._lib.lib().wd_deform_conv3x3_variant
+    name.restype = __import__('ctypes').c_char_p
+    assert b'pp_kernel' in name(C, C // 32, 1, 1, 1)
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn((batch, C, H, W), generator=g)
+    offset = torch.randn((batch, 18, H, W), generator=g) * off_std
+    weight = torch.randn((C, 32, 3, 3), generator=g) / (3 * 32 ** 0.5)
+    scale = torch.rand(C, generator=g) + 0.5
+    bias = torch.randn(C, generator=g)
+    exp = R.deform_conv3x3(x, offset, weight, C // 32, 1, 1, None)
+    packed = ops.deform_pack_weight(weight.cuda(), C // 32)
+    got = ops.deform_conv3x3(_cl(x), _cl(offset), packed, C // 32, 1, 1)
+    np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-4)
+    got2 = ops.deform_conv3x3(_cl(x), _cl(offset), packed, C // 32, 1, 1, scale=scale.cuda(), bias=bias.cuda(), relu=True)
+    exp2 = torch.relu(exp * scale.double()[None, :, None, None] + bias.double()[None, :, None, None])
+    np.testing.assert_allclose(got2.cpu().double().numpy(), exp2.numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_decode_boxes_is_bit_identical_to_the_torch_sequence():
     """wd_decode_boxes_f32 == apply_deltas + clip_boxes (detectron2 Box2BoxTransform / Boxes.clip restated in
     cascade_rcnn.py), bit for bit, with and without gather index / clipping; huge dw hits the scale clamp."""

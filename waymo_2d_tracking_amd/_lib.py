@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'csrc', 'libwaymotrack.so')
+LIB_PATH = os.environ.get('WT_LIB_PATH') or os.path.join(HERE, 'csrc', 'libwaymotrack.so')    # WT_LIB_PATH: kernel experiments
 
 WT_OK = 0
 _STATUS = {1: 'WT_ERR_INVALID', 2: 'WT_ERR_NO_DEVICE', 3: 'WT_ERR_HIP', 4: 'WT_ERR_CAPACITY', 5: 'WT_ERR_NUMERIC'}

@@ -30,6 +30,7 @@ UNITS = {
     'det_roialign.hip': [],
     'det_nms.hip': [],
     'det_deform.hip': [],
+    'det_deform_pp.hip': [],
     'det_gemm.hip': ['-munsafe-fp-atomics'],
     'det_misc.hip': [],
     'det_preprocess.hip': ['-ffp-contract=off'],
