@@ -5,6 +5,8 @@ the result is ``[per image][per class] ndarray (n,5) float32 [score, cx/W, cy/H,
 arrays for classes without detections (:119-135).  The graph is the MI355X-native Cascade R-CNN of cascade_rcnn.py
 instead of a detectron2 model; ``predict_device`` is the device-resident form used by the end-to-end pipeline.
 """
+import os
+
 import numpy as np
 import torch
 from torch.nn import Module
@@ -15,15 +17,74 @@ from .cascade_rcnn import CascadeRCNN, PIXEL_MEAN, PIXEL_STD
 WAYMO_CLASSNAMES = ('vehicle', 'pedestrian', 'sign', 'cyclist')      # category ids 1..4 (waymo_to_coco.py:19,36)
 
 
+# the detectron2 model-zoo checkpoint the reference downloads for pretrained='coco' (logs/12442/job.log:1226); there is no
+# network here: the file has to be provided
+COCO_CHECKPOINT = 'Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv/18131413/model_0039999_e76410.pkl'
+
+
+def find_pretrained_checkpoint():
+    """$WAYMO_DETECTRON2_WEIGHTS (a file), or the detectron2 / fvcore cache locations of the model-zoo file."""
+    cands = [os.environ.get('WAYMO_DETECTRON2_WEIGHTS', '')]
+    for root in (os.environ.get('FVCORE_CACHE', ''), os.path.expanduser('~/.torch/fvcore_cache'), os.path.expanduser('~/.torch/iopath_cache')):
+        if root:
+            cands.append(os.path.join(root, 'detectron2', COCO_CHECKPOINT))
+    for c in cands:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
 class Detectron2Det(Module):
+    """detectron2_det/__init__.py:63-68, same constructor arguments.  `pretrained == 'coco'` loads the detectron2 model-zoo
+    checkpoint (found through find_pretrained_checkpoint(); a missing file raises - there is no silent random-weight
+    fallback); any other value builds the graph with seeded random weights (benchmarks, tests, or a later load_state_dict).
+    `freeze_pretrained` = cfg.MODEL.BACKBONE.FREEZE_AT (:44); `frozen_bn` False (trainable BatchNorm) is not built."""
+
     def __init__(self, arch='Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml', classnames=WAYMO_CLASSNAMES,
                  freeze_pretrained=2, frozen_bn=True, pretrained=False, seed=0):
         super().__init__()
         if 'X_152' not in arch:
             raise NotImplementedError('only the Cascade R-CNN X-152-32x8d-FPN dconv graph of the Waymo solution is built')
+        if not frozen_bn:
+            raise NotImplementedError('MODEL.RESNETS.NORM = "BN" (frozen_bn=False) is not built: the solution trains with FrozenBN')
         self.arch = arch
-        self.classnames = list(classnames)
+        self.classnames = list(classnames) if classnames else list(WAYMO_CLASSNAMES)
+        self.freeze_at = int(freeze_pretrained)
         self.model = CascadeRCNN(num_classes=len(self.classnames), seed=seed)
+        self.tta_min_sizes = None
+        if pretrained == 'coco':
+            path = find_pretrained_checkpoint()
+            if path is None:
+                raise FileNotFoundError(
+                    "pretrained='coco' needs the detectron2 checkpoint %s: set WAYMO_DETECTRON2_WEIGHTS to the file "
+                    "(no network access here; random weights are only used when pretrained is not 'coco')" % COCO_CHECKPOINT)
+            self.load_detectron2(path)
+
+    def load_detectron2(self, path_or_state_dict, strict=None):
+        """Load a detectron2 `.pkl` / `.pth` or a reference `{args, kwargs, state_dict}` file (or a state dict).  The COCO
+        checkpoint has 80-class predictors: like DetectionCheckpointer the mismatching cls_score / bbox_pred tensors are
+        skipped (left at their initialisation) when strict is None."""
+        from . import weights
+        sd = path_or_state_dict if isinstance(path_or_state_dict, dict) else weights.load_checkpoint_file(path_or_state_dict)
+        sd = weights._strip(sd)
+        if strict is None:
+            want = {n: s for n, s, _ in weights.detectron2_layout(self.model.num_classes)}
+            drop = [n for n in sd if n in want and list(sd[n].shape) != want[n] and '.box_predictor.' in n]
+            for n in drop:
+                del sd[n]
+            mask_keys = [n for n in sd if n.startswith('roi_heads.mask_')]      # MASK_ON False (:54)
+            for n in mask_keys:
+                del sd[n]
+            return weights.load_state_dict_detectron2(self.model, sd, strict=False)
+        return weights.load_state_dict_detectron2(self.model, sd, strict=strict)
+
+    def enable_tta(self, min_sizes=None):
+        """detectron2_det/__init__.py:188-196: wrap the model in detectron2's GeneralizedRCNNWithTTA with TEST.AUG.FLIP False:
+        predict() then runs one pass per TEST.AUG.MIN_SIZES entry (shortest edge resized, max size 4000 - detectron2's
+        defaults (400, 500, 600, 700, 800, 900, 1000, 1100, 1200)) and merges all boxes with the final per-class NMS."""
+        if self.tta_min_sizes is None:
+            self.tta_min_sizes = list(min_sizes) if min_sizes else [400, 500, 600, 700, 800, 900, 1000, 1100, 1200]
+            print(f'TEST.AUG.MIN_SIZES={self.tta_min_sizes}')
 
     def forward(self, x):
         """detectron2_det/__init__.py:70-74: RGB -> BGR (INPUT.FORMAT == 'BGR')."""
@@ -36,9 +97,34 @@ class Detectron2Det(Module):
         forward() (:70-74), detectron2's normalisation and the padding to a multiple of 32; boxes are in pixels of the
         transformed (resized / flipped) image, like the reference's detector sees it."""
         dev = next(self.parameters()).device
+        if self.tta_min_sizes:
+            return self._predict_multiscale(x.to(dev), scale, hflip, vflip)
         xn, (ho, wo) = ops.preprocess(x.to(dev), scale, hflip, vflip, True, PIXEL_MEAN, PIXEL_STD, 32)
         self.last_input_size = (ho, wo)
         return [self.model.forward_normalized(xn[i:i + 1], ho, wo) for i in range(xn.shape[0])]
+
+    def _predict_multiscale(self, x, scale, hflip, vflip, max_size=4000):
+        """enable_tta(): GeneralizedRCNNWithTTA restated (detectron2 0.1.3 modeling/test_time_augmentation.py, FLIP False): one
+        detector pass per min size (ResizeShortestEdge), boxes rescaled to the base image, all detections merged by the model's
+        own score threshold + per-class NMS + top-k.  Arithmetic unpinned (detectron2 absent), structure from the call site."""
+        h0 = x.shape[2] if x.dtype != torch.uint8 else x.shape[1]
+        w0 = x.shape[3] if x.dtype != torch.uint8 else x.shape[2]
+        hb, wb = int(h0 * scale), int(w0 * scale)                 # the image the reference's TTA wrapper would be handed
+        self.last_input_size = (hb, wb)
+        out = []
+        for i in range(x.shape[0]):
+            bs, ss, cs = [], [], []
+            for ms in self.tta_min_sizes:
+                f = ms / float(min(hb, wb))
+                if max(hb, wb) * f > max_size:
+                    f = max_size / float(max(hb, wb))
+                xn, (ho, wo) = ops.preprocess(x[i:i + 1], scale * f, hflip, vflip, True, PIXEL_MEAN, PIXEL_STD, 32)
+                b, s, c = self.model.forward_normalized(xn, ho, wo)
+                bs.append(b * torch.tensor([wb / wo, hb / ho, wb / wo, hb / ho], device=b.device)); ss.append(s); cs.append(c)
+            b, s, c = torch.cat(bs), torch.cat(ss), torch.cat(cs)
+            keep = ops.batched_nms(b, s, c.to(torch.int32), self.model.nms_thresh)[: self.model.topk] if s.numel() else s.new_zeros(0, dtype=torch.long)
+            out.append((b[keep], s[keep], c[keep]))
+        return out
 
     def criterion(self, args=None):
         """detectron2_det/__init__.py:141-142"""

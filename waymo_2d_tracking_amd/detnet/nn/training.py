@@ -64,8 +64,9 @@ class _ScaleGradient(torch.autograd.Function):
         return g * ctx.scale, None
 
 
-def rpn_losses(rpn, feats, gt_boxes, img_h, img_w, batch_per_image=256, pos_frac=0.5, pre_nms=2000, post_nms=2000):
-    """RPN head on p2..p6 -> (losses, proposals for the ROI heads (detached))."""
+def rpn_losses(rpn, feats, gt_boxes, img_h, img_w, batch_per_image=256, pos_frac=0.5, pre_nms=2000, post_nms=1000):
+    """RPN head on p2..p6 -> (losses, proposals for the ROI heads (detached)).
+    detectron2_det/configs/Base-RCNN-FPN.yaml: PRE_NMS_TOPK_TRAIN 2000 (per level), POST_NMS_TOPK_TRAIN 1000 (per image)."""
     logits_l, deltas_l, anchors_l = [], [], []
     boxes_l, scores_l, lvl_l = [], [], []
     for l, f in enumerate(feats):
