@@ -38,15 +38,16 @@ class Detectron2Det(Module):
     """detectron2_det/__init__.py:63-68, same constructor arguments.  `pretrained == 'coco'` loads the detectron2 model-zoo
     checkpoint (found through find_pretrained_checkpoint(); a missing file raises - there is no silent random-weight
     fallback); any other value builds the graph with seeded random weights (benchmarks, tests, or a later load_state_dict).
-    `freeze_pretrained` = cfg.MODEL.BACKBONE.FREEZE_AT (:44); `frozen_bn` False (trainable BatchNorm) is not built."""
+    `freeze_pretrained` = cfg.MODEL.BACKBONE.FREEZE_AT (:44)."""
 
     def __init__(self, arch='Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml', classnames=WAYMO_CLASSNAMES,
                  freeze_pretrained=2, frozen_bn=True, pretrained=False, seed=0):
         super().__init__()
         if 'X_152' not in arch:
             raise NotImplementedError('only the Cascade R-CNN X-152-32x8d-FPN dconv graph of the Waymo solution is built')
-        if not frozen_bn:
-            raise NotImplementedError('MODEL.RESNETS.NORM = "BN" (frozen_bn=False) is not built: the solution trains with FrozenBN')
+        # frozen_bn False = MODEL.RESNETS.NORM "BN" (:45): in eval mode BatchNorm applies its running statistics exactly like
+        # FrozenBatchNorm, so inference is identical; TRAINING with trainable BatchNorm is not built (loss() raises)
+        self.frozen_bn = bool(frozen_bn)
         self.arch = arch
         self.classnames = list(classnames) if classnames else list(WAYMO_CLASSNAMES)
         self.freeze_at = int(freeze_pretrained)
@@ -134,6 +135,8 @@ class Detectron2Det(Module):
         """detectron2_det/__init__.py:144-186: images (B,3,H,W) RGB 0..255, target = {'labels': [LongTensor (n_i) 1-based],
         'boxes': [Tensor (n_i,4) xyxy pixels]} -> dict of loss tensors (summed over the batch / B)."""
         from . import training
+        if not self.frozen_bn:
+            raise NotImplementedError('training with MODEL.RESNETS.NORM = "BN" (frozen_bn=False) is not built: the solution trains with FrozenBN')
         x = self(images.to(next(self.parameters())))
         total = {}
         for i in range(x.shape[0]):
