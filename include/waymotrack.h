@@ -196,6 +196,28 @@ const char* wt_detfile_camera(const wt_detfile* f, int32_t stream);
  *   "object_id": "<id>"}, ...]; floats in Python repr form.  Rows as produced by wt_track_streams_*. */
 int wt_tracks_write_json(const char* path, const wt_detfile* f, int64_t n, const int64_t* frame, const int32_t* category,
                          const double* bbox4, const double* score, const int64_t* object_id);
+/* Generic detection JSON = the wire format between inference, ensemble and tracking (detnet/data/coco.py:229-252,
+ * detnet/ensemble.py:59-63,79,159-160): a list of {"image_id": str, "category_id": int, "bbox": [x, y, w, h], "score": float}.
+ * wt_detjson_read = json.load of such a file into columns (image ids interned in first-appearance order; every entry must carry
+ * the four keys, like convert_submission's det['score'] / det['bbox'] lookups, ensemble.py:35-45).
+ * wt_detections_write_json = json.dump of rows whose boxes are integers (coco.py:250 int(v), ensemble.py:62 astype(int)) and whose
+ * scores were rounded by the caller; key order image_id, category_id, bbox, score; strings escaped like json.dumps (ensure_ascii).
+ * image ids: UTF-8 blob + (n_images + 1) offsets. */
+typedef struct wt_detjson wt_detjson;
+int wt_detjson_read(const char* path, wt_detjson** out);
+void wt_detjson_free(wt_detjson* f);
+int64_t wt_detjson_num_rows(const wt_detjson* f);
+int32_t wt_detjson_num_images(const wt_detjson* f);
+const int32_t* wt_detjson_image(const wt_detjson* f);
+const int32_t* wt_detjson_category(const wt_detjson* f);
+const double* wt_detjson_x(const wt_detjson* f);
+const double* wt_detjson_y(const wt_detjson* f);
+const double* wt_detjson_w(const wt_detjson* f);
+const double* wt_detjson_h(const wt_detjson* f);
+const double* wt_detjson_score(const wt_detjson* f);
+const char* wt_detjson_image_id(const wt_detjson* f, int32_t i);
+int wt_detections_write_json(const char* path, int64_t n, const int32_t* image_index, int32_t n_images, const char* image_id_blob,
+                             const int64_t* image_id_offsets, const int32_t* category, const int64_t* bbox4, const double* score);
 /* Python repr() of a double (shortest round-trip digits); returns the length or -1 if cap is too small. */
 int wt_format_double(double v, char* out, int cap);
 

@@ -54,6 +54,80 @@ def test_sharded_tracking_world2_matches_reference(tmp_path, golden_dir, oracle)
     np.testing.assert_allclose(gb, eb, rtol=0, atol=1e-6)
 
 
+def _oracle_merge_fn(packed, k_inputs, method, iou_thresh, soft_nms_cut):
+    from oracle import oracle as O
+    from waymo_2d_tracking_amd.detnet.ensemble import METHODS
+    out5, counts = O.ensemble_groups(packed['dets5'], packed['group_offsets'], packed['input_sizes'], k_inputs, METHODS[method],
+                                     iou_thresh, soft_nms_cut)
+    return out5, counts
+
+
+def _collate_worker(rank, world_size, port, golden, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    from waymo_2d_tracking_amd import distributed as D
+    from waymo_2d_tracking_amd.detnet import ensemble as E
+    from waymo_2d_tracking_amd.detnet.trainer import Predictions
+    # (a) ragged columnar gather: rank r contributes 3 + 4 r rows (rank 1 more than rank 0), 1-D and 2-D columns
+    n = 3 + 4 * rank
+    cols = dict(a=np.arange(n, dtype=np.int64) + 100 * rank, b=np.full((n, 4), rank + 0.5), c=np.arange(n, dtype=np.int32))
+    got = D.gather_columns_rank0(cols)
+    if rank == 0:
+        assert got['a'].tolist() == [0, 1, 2] + [100 + i for i in range(7)]
+        assert got['b'].shape == (10, 4) and got['b'][:3].max() == 0.5 and got['b'][3:].min() == 1.5 and got['c'].dtype == np.int32
+    else:
+        assert got is None
+    empty = D.gather_columns_rank0(dict(a=np.zeros(0 if rank == 0 else 2, np.float64)))
+    assert rank != 0 or empty['a'].shape == (2,)
+    # (b) ensemble: images sharded in contiguous blocks, rows gathered to rank 0 == the single-process result (G2)
+    exp = json.load(open(os.path.join(golden, 'ensemble_g2_expected.json')))
+    files = [os.path.join(golden, 'ensemble_g2_input%d.json' % i) for i in range(3)]
+    subs = [E.submission_columns(json.load(open(f))) for f in files]
+    image_ids, category_ids, rows = E.merge_inputs(subs, exp['weights'], exp['min_score'])
+    out = E.ensemble_columns(image_ids, category_ids, rows, 3, 'soft_nms', exp['iou_thresh'], exp['soft_nms_cut'], exp['min_score'],
+                             merge_fn=_oracle_merge_fn)
+    if rank == 0:
+        json.dump([{'image_id': image_ids[i], 'category_id': int(c), 'bbox': b, 'score': s} for i, c, b, s in
+                   zip(out['image'].tolist(), out['category'].tolist(), out['bbox'].tolist(), out['score'].tolist())],
+                  open(os.path.join(out_dir, 'ens.json'), 'wt'))
+    # (c) inference collation: each rank fills a store for its contiguous block of images, one gather, rank 0 merges
+    g6 = json.load(open(os.path.join(golden, 'export_g6.json')))
+    ids = list(g6['images'])
+    lo, hi = D.contiguous_split(len(ids), world_size)[rank]
+    store = Predictions(g6['classnames'], ids)
+    for image_id in ids[lo:hi]:
+        store[image_id] = [np.asarray(d, np.float32).reshape(-1, 5) for d in g6['predictions'][image_id]]
+    cols, tested = store.shard_columns()
+    allc = D.gather_columns_rank0(cols)
+    allt = D.gather_columns_rank0(dict(tested=tested.astype(np.uint8)))
+    if rank == 0:
+        from waymo_2d_tracking_amd.detnet import export as X
+        full = Predictions.from_shards(g6['classnames'], ids, [allc], [allt['tested'].reshape(world_size, -1).any(0)])
+        r = X.detection_rows(full, {k: (v['width'], v['height']) for k, v in g6['images'].items()})
+        json.dump(dict(image=[ids[i] for i in r['image']], category=r['category'].tolist(), bbox=r['bbox'].tolist()),
+                  open(os.path.join(out_dir, 'inf.json'), 'wt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collation_world2_columns_ensemble_inference(tmp_path, golden_dir, oracle):
+    """§8f-2: tensor collation (counts all_gather + one padded gather, no pickling) under gloo, world size 2, for the three
+    CLIs' row sets; the sharded ensemble reproduces the reference-generated G2 rows."""
+    from test_oracle_ensemble import assert_json_rows_equal
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_collate_worker, args=(2, port, golden_dir, str(tmp_path)), nprocs=2, join=True)
+    exp = json.load(open(os.path.join(golden_dir, 'ensemble_g2_expected.json')))
+    got = json.load(open(tmp_path / 'ens.json'))
+    key = lambda r: (r['image_id'], r['category_id'], -r['score'], r['bbox'])
+    assert_json_rows_equal(sorted(got, key=key), sorted(exp['outputs']['soft_nms'], key=key))
+    g6 = json.load(open(os.path.join(golden_dir, 'export_g6.json')))
+    inf = json.load(open(tmp_path / 'inf.json'))
+    assert inf['image'] == [r['image_id'] for r in g6['rows']] and inf['bbox'] == [r['bbox'] for r in g6['rows']]
+    assert inf['category'] == [r['category_id'] for r in g6['rows']]
+
+
 def test_splits():
     from waymo_2d_tracking_amd import distributed as D
     assert D.contiguous_split(10, 3) == [(0, 3), (3, 6), (6, 10)]                 # trainer/data/__init__.py:9-18

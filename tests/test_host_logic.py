@@ -37,12 +37,75 @@ def test_ensemble_cli_refuses_existing_output_and_parses(tmp_path, golden_dir):
     with pytest.raises(RuntimeError):                                           # ensemble.py:131-132
         E.main([os.path.join(golden_dir, 'ensemble_g2_input0.json'), os.path.join(golden_dir, 'ensemble_g2_input1.json'),
                 '-o', str(out), '-m', 'soft_nms'])
-    subs = [json.load(open(os.path.join(golden_dir, 'ensemble_g2_input%d.json' % i))) for i in range(2)]
-    dets = [E.convert_submission(s, 1.0, 0.01) for s in subs]
-    packed = E.pack_groups(sorted(dets[0].keys()), [1, 2, 4], dets)
-    assert packed['group_offsets'][-1] == len(packed['dets5'])
-    assert packed['input_sizes'].shape == (len(packed['keys']), 2)
-    assert packed['input_sizes'].sum() == len(packed['dets5'])
+    # column path: native reader == json.load, grouping == the dict path of the reference
+    files = [os.path.join(golden_dir, 'ensemble_g2_input%d.json' % i) for i in range(2)]
+    subs = [json.load(open(f)) for f in files]
+    for f, s in zip(files, subs):
+        nat, ref = E.read_submission(f), E.submission_columns(s)
+        assert nat['image_ids'] == ref['image_ids']
+        for k in ('image', 'category', 'x', 'y', 'w', 'h', 'score'):
+            assert np.array_equal(nat[k], ref[k]), k
+    image_ids, category_ids, rows = E.load_input_submissions(files, [1.0, 0.5], 0.01)
+    dets = [E.convert_submission(s, w, 0.01) for s, w in zip(subs, [1.0, 0.5])]
+    assert set(image_ids) == set(k for d in dets for k in d) and category_ids == [1, 2, 4]
+    packed = E.pack_groups(len(image_ids), category_ids, rows, 2)
+    assert packed['group_offsets'][-1] == len(packed['dets5']) == len(rows['score'])
+    assert packed['input_sizes'].shape == (len(image_ids) * 3, 2) and packed['input_sizes'].sum() == len(packed['dets5'])
+    for gi in (0, 4, len(image_ids) * 3 - 1):                     # rows of a group: input 0 then input 1, file order
+        image_id, cat = image_ids[gi // 3], category_ids[gi % 3]
+        want = [r for d in dets for r in d.get(image_id, {}).get(cat, [])]
+        got = packed['dets5'][packed['group_offsets'][gi]:packed['group_offsets'][gi + 1]]
+        assert np.array_equal(got, np.asarray(want, np.float64).reshape(-1, 5))
+    # blocks of images (multi-GPU shards) partition the groups
+    a, b = E.pack_groups(len(image_ids), category_ids, rows, 2, 0, 5), E.pack_groups(len(image_ids), category_ids, rows, 2, 5, len(image_ids))
+    assert np.array_equal(np.vstack((a['dets5'], b['dets5'])), packed['dets5'])
+
+
+def test_native_detection_json_writer_is_byte_identical_to_json_dump(tmp_path, golden_dir):
+    """wt_detections_write_json == json.dump of the reference's row dicts (coco.py:249-251, ensemble.py:61-62) on G2 / G6
+    rows and on strings that need escaping."""
+    from waymo_2d_tracking_amd.detnet.export import write_detections_json
+    cases = [json.load(open(os.path.join(golden_dir, 'ensemble_g2_expected.json')))['outputs']['soft_nms'],
+             json.load(open(os.path.join(golden_dir, 'export_g6.json')))['rows'],
+             [{'image_id': 'a"b\\c/\u00fc/\u4e2d\U0001F600\n\x7f', 'category_id': 1, 'bbox': [1, -2, 3, 4], 'score': 1e-07}], []]
+    for i, rows in enumerate(cases):
+        ids = list(dict.fromkeys(r['image_id'] for r in rows))
+        ix = {k: j for j, k in enumerate(ids)}
+        cols = dict(image=np.array([ix[r['image_id']] for r in rows], np.int32), category=np.array([r['category_id'] for r in rows], np.int32),
+                    bbox=np.array([r['bbox'] for r in rows], np.int64).reshape(-1, 4), score=np.array([r['score'] for r in rows], np.float64))
+        out = tmp_path / ('w%d.json' % i)
+        write_detections_json(out, ids, cols)
+        assert open(out).read() == json.dumps(rows), i
+
+
+def test_prediction_store_and_export_rows(golden_dir):
+    """Predictions (columnar trainer/predictions.py) keeps the mapping interface; export rows == load_prediction on G6."""
+    from waymo_2d_tracking_amd.detnet.trainer import Predictions
+    from waymo_2d_tracking_amd.detnet import export as X
+    g6 = json.load(open(os.path.join(golden_dir, 'export_g6.json')))
+    classnames = g6['classnames']
+    p = Predictions(classnames)
+    sizes = {}
+    for image_id, info in g6['images'].items():
+        p[image_id] = [np.asarray(d, np.float32).reshape(-1, 5) for d in g6['predictions'][image_id]]
+        sizes[image_id] = (info['width'], info['height'])
+    assert len(p) == len(g6['images']) and set(p.keys()) == set(g6['images'])
+    first = next(iter(g6['images']))
+    got = p[first]
+    assert len(got) == 4 and all(np.array_equal(a, np.asarray(b, np.float32).reshape(-1, 5)) for a, b in zip(got, g6['predictions'][first]))
+    assert p['missing'] is None
+    rows = X.detection_rows(p, sizes)
+    exp = g6['rows']
+    assert [p.image_ids[i] for i in rows['image']] == [r['image_id'] for r in exp]
+    assert rows['category'].tolist() == [r['category_id'] for r in exp]
+    assert rows['bbox'].tolist() == [r['bbox'] for r in exp]
+    assert np.abs(rows['score'] - np.array([r['score'] for r in exp])).max() <= 1.0000001e-5      # half-way rounding, see DESIGN 2
+    # shards -> one store; save / open
+    a, b = Predictions(classnames, p.image_ids), Predictions(classnames, p.image_ids)
+    for k, (image_id, det) in enumerate(p):
+        (a if k % 2 == 0 else b)[image_id] = det
+    merged = Predictions.from_shards(classnames, p.image_ids, [a.shard_columns()[0], b.shard_columns()[0]], [a.tested, b.tested])
+    assert len(merged) == len(p) and all(np.array_equal(x, y) for k in p.keys() for x, y in zip(merged[k], p[k]))
 
 
 def test_yaml_weights_loader():

@@ -113,6 +113,51 @@ struct wt_detfile {
     std::vector<std::string> segment, camera;     // per stream
 };
 
+
+// generic detection JSON (list of {image_id, category_id, bbox [x, y, w, h], score}): ensemble inputs (detnet/ensemble.py:79)
+struct wt_detjson {
+    std::vector<int32_t> image, category;
+    std::vector<double> x, y, w, h, score;
+    std::vector<std::string> image_ids;            // first-appearance order
+};
+
+// json.dumps(str) with ensure_ascii=True
+static void py_json_string(const std::string& s, std::string& out) {
+    out += '"';
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(s.data());
+    const unsigned char* e = p + s.size();
+    char tmp[16];
+    while (p < e) {
+        unsigned c = *p;
+        if (c == '"') { out += "\\\""; ++p; }
+        else if (c == '\\') { out += "\\\\"; ++p; }
+        else if (c == '\n') { out += "\\n"; ++p; }
+        else if (c == '\r') { out += "\\r"; ++p; }
+        else if (c == '\t') { out += "\\t"; ++p; }
+        else if (c == '\b') { out += "\\b"; ++p; }
+        else if (c == '\f') { out += "\\f"; ++p; }
+        else if (c < 0x20 || c == 0x7F) { snprintf(tmp, sizeof(tmp), "\\u%04x", c); out += tmp; ++p; }     // json: everything outside ' '..'~'
+
+        else if (c < 0x80) { out += (char)c; ++p; }
+        else {
+            // UTF-8 -> code point -> \uXXXX (surrogate pair above the BMP)
+            unsigned cp = 0xFFFD; int len = 1;
+            if ((c & 0xE0) == 0xC0 && p + 1 < e) { cp = ((c & 0x1F) << 6) | (p[1] & 0x3F); len = 2; }
+            else if ((c & 0xF0) == 0xE0 && p + 2 < e) { cp = ((c & 0x0F) << 12) | ((p[1] & 0x3F) << 6) | (p[2] & 0x3F); len = 3; }
+            else if ((c & 0xF8) == 0xF0 && p + 3 < e) { cp = ((c & 0x07) << 18) | ((p[1] & 0x3F) << 12) | ((p[2] & 0x3F) << 6) | (p[3] & 0x3F); len = 4; }
+            if (cp >= 0x10000) {
+                cp -= 0x10000;
+                snprintf(tmp, sizeof(tmp), "\\u%04x\\u%04x", 0xD800 + (cp >> 10), 0xDC00 + (cp & 0x3FF));
+            } else {
+                snprintf(tmp, sizeof(tmp), "\\u%04x", cp);
+            }
+            out += tmp;
+            p += len;
+        }
+    }
+    out += '"';
+}
+
 // Python float repr (shortest round-trip digits; exponent form iff decpt <= -4 or decpt > 16)
 static int py_float_repr(double v, char* out) {
     if (v != v) return sprintf(out, "NaN");
@@ -342,6 +387,111 @@ int wt_tracks_write_json(const char* path, const wt_detfile* f, int64_t n, const
         buf += ", \"object_id\": \"";
         buf += std::to_string((long long)object_id[i]);
         buf += "\"}";
+        if (buf.size() > (1 << 20) - 512) { fwrite(buf.data(), 1, buf.size(), fp); buf.clear(); }
+    }
+    buf += ']';
+    fwrite(buf.data(), 1, buf.size(), fp);
+    fclose(fp);
+    return WT_OK;
+}
+
+/* ---- generic detection JSON: reader for the ensemble inputs, writer for detection / ensemble outputs ---- */
+int wt_detjson_read(const char* path, wt_detjson** out) {
+    if (!path || !out) { wt::set_error("wt_detjson_read: bad argument"); return WT_ERR_INVALID; }
+    *out = nullptr;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) { wt::set_error("cannot open %s", path); return WT_ERR_INVALID; }
+    fseek(fp, 0, SEEK_END);
+    const long size = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::string text((size_t)size, '\0');
+    const size_t got = fread(&text[0], 1, (size_t)size, fp);
+    fclose(fp);
+    if (got != (size_t)size) { wt::set_error("short read on %s", path); return WT_ERR_INVALID; }
+    Parser ps{text.data(), text.data() + text.size(), {}};
+    if (!ps.lit('[')) { wt::set_error("%s: expected a JSON list", path); return WT_ERR_INVALID; }
+    wt_detjson* f = new wt_detjson;
+    std::unordered_map<std::string, int> index;
+    std::string key, image_id;
+    if (!ps.lit(']')) {
+        do {
+            if (!ps.lit('{')) { ps.fail("expected {"); break; }
+            double b[4] = {0, 0, 0, 0}, score = 0, cat = 0;
+            bool have_id = false, have_bbox = false, have_score = false, have_cat = false;
+            if (!ps.lit('}')) {
+                do {
+                    if (!ps.string(key) || !ps.lit(':')) break;
+                    if (key == "image_id") { if (!ps.string(image_id)) break; have_id = true; }
+                    else if (key == "category_id") { if (!ps.number(cat)) break; have_cat = true; }
+                    else if (key == "score") { if (!ps.number(score)) break; have_score = true; }
+                    else if (key == "bbox") {
+                        if (!ps.lit('[')) { ps.fail("expected ["); break; }
+                        bool ok = true;
+                        for (int i = 0; i < 4 && ok; ++i) ok = ps.number(b[i]) && (i == 3 || ps.lit(','));
+                        if (!ok || !ps.lit(']')) { ps.fail("bbox must have 4 numbers"); break; }
+                        have_bbox = true;
+                    } else if (!ps.skip()) break;
+                } while (ps.lit(','));
+                if (!ps.err.empty() || !ps.lit('}')) { ps.fail("expected }"); break; }
+            }
+            if (!have_id || !have_bbox || !have_score || !have_cat) { ps.fail("entry without image_id / category_id / bbox / score"); break; }
+            auto it = index.find(image_id);
+            int ii;
+            if (it == index.end()) { ii = (int)f->image_ids.size(); index.emplace(image_id, ii); f->image_ids.push_back(image_id); }
+            else ii = it->second;
+            f->image.push_back(ii); f->category.push_back((int32_t)cat);
+            f->x.push_back(b[0]); f->y.push_back(b[1]); f->w.push_back(b[2]); f->h.push_back(b[3]); f->score.push_back(score);
+        } while (ps.lit(','));
+        if (ps.err.empty() && !ps.lit(']')) ps.fail("expected ]");
+    }
+    if (!ps.err.empty()) { wt::set_error("%s: %s", path, ps.err.c_str()); delete f; return WT_ERR_INVALID; }
+    *out = f;
+    return WT_OK;
+}
+void wt_detjson_free(wt_detjson* f) { delete f; }
+int64_t wt_detjson_num_rows(const wt_detjson* f) { return f ? (int64_t)f->x.size() : 0; }
+int32_t wt_detjson_num_images(const wt_detjson* f) { return f ? (int32_t)f->image_ids.size() : 0; }
+const int32_t* wt_detjson_image(const wt_detjson* f) { return f->image.data(); }
+const int32_t* wt_detjson_category(const wt_detjson* f) { return f->category.data(); }
+const double* wt_detjson_x(const wt_detjson* f) { return f->x.data(); }
+const double* wt_detjson_y(const wt_detjson* f) { return f->y.data(); }
+const double* wt_detjson_w(const wt_detjson* f) { return f->w.data(); }
+const double* wt_detjson_h(const wt_detjson* f) { return f->h.data(); }
+const double* wt_detjson_score(const wt_detjson* f) { return f->score.data(); }
+const char* wt_detjson_image_id(const wt_detjson* f, int32_t i) { return f->image_ids[(size_t)i].c_str(); }
+
+int wt_detections_write_json(const char* path, int64_t n, const int32_t* image_index, int32_t n_images, const char* image_id_blob,
+                             const int64_t* image_id_offsets, const int32_t* category, const int64_t* bbox4, const double* score) {
+    if (!path || n < 0 || n_images < 0 || (n && (!image_index || !category || !bbox4 || !score || !image_id_blob || !image_id_offsets))) {
+        wt::set_error("wt_detections_write_json: bad argument");
+        return WT_ERR_INVALID;
+    }
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { wt::set_error("cannot open %s for writing", path); return WT_ERR_INVALID; }
+    std::vector<std::string> ids((size_t)n_images);             // escaped once per image
+    for (int32_t i = 0; i < n_images; ++i)
+        py_json_string(std::string(image_id_blob + image_id_offsets[i], (size_t)(image_id_offsets[i + 1] - image_id_offsets[i])), ids[(size_t)i]);
+    std::string buf;
+    buf.reserve(1 << 20);
+    buf += '[';
+    char num[64];
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t im = image_index[i];
+        if (im < 0 || im >= n_images) { fclose(fp); wt::set_error("row %lld: image index out of range", (long long)i); return WT_ERR_INVALID; }
+        if (i) buf += ", ";
+        buf += "{\"image_id\": ";
+        buf += ids[(size_t)im];
+        buf += ", \"category_id\": ";
+        buf += std::to_string((int)category[i]);
+        buf += ", \"bbox\": [";
+        for (int q = 0; q < 4; ++q) {
+            if (q) buf += ", ";
+            buf += std::to_string((long long)bbox4[4 * i + q]);
+        }
+        buf += "], \"score\": ";
+        py_float_repr(score[i], num);
+        buf += num;
+        buf += '}';
         if (buf.size() > (1 << 20) - 512) { fwrite(buf.data(), 1, buf.size(), fp); buf.clear(); }
     }
     buf += ']';

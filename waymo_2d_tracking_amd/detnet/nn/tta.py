@@ -3,7 +3,8 @@
 ``nms_detections`` / ``merge_detections`` keep the reference signatures (tta.py:8, :22) on lists of
 ``(n_i, 5) [score, cx, cy, w, h]`` arrays; the arithmetic runs in the batched ensemble kernel
 (``wt_ensemble_groups_host``, one wavefront per call here, thousands per call from detnet.ensemble).
-The TTA operator algebra (tta.py:69-267) is host-side tensor plumbing around ``detector.predict``.
+Test-time augmentation (tta.py:69-267) is a parsed plan of image operations around ``detector.predict``; on the Waymo setting the
+plan folds into the detector's fused pre-processing kernel.
 """
 import ctypes as C
 
@@ -41,145 +42,66 @@ def merge_detections(detections, nms_thresh=0.5):
     return _run_group(detections, 0, nms_thresh, 1.0)
 
 
-class OpTTA(object):
-    def pre_process(self, x):
-        raise NotImplementedError
-
-    def post_process(self, y):
-        raise NotImplementedError
-
-
-class Compose(OpTTA, list):
-    pass
-
-
-class SequentialTTA(Compose):
-    """tta.py:107-116"""
-
-    def pre_process(self, x):
-        for tta in self:
-            x = tta.pre_process(x)
-        return x
-
-    def post_process(self, y):
-        for tta in self[::-1]:
-            y = tta.post_process(y)
-        return y
+def parse_tta(data_aug):
+    """`--tta` tokens -> the ordered list of image operations the reference's TTA.__init__ builds (tta.py:228-258):
+    every `xS` resize in the given order, then hflip, then vflip ('orig' is the identity).  The brute / dflip / batch modes
+    of the reference are not on the Waymo path (`--tta x1.5,hflip`, README.md:37)."""
+    for unsupported in ('brute', 'dflip', 'batch'):
+        if unsupported in data_aug:
+            raise NotImplementedError('TTA mode %r is not part of the Waymo hot path' % unsupported)
+    plan = [('resize', float(tok[1:])) for tok in data_aug if tok.startswith('x')]
+    plan += [(flip,) for flip in ('hflip', 'vflip') if flip in data_aug]
+    known = {'orig', 'hflip', 'vflip'}
+    bad = [tok for tok in data_aug if tok not in known and not tok.startswith('x')]
+    if bad:
+        raise ValueError('unknown TTA token(s) %s' % bad)
+    return plan
 
 
-class ParallelTTA(Compose):
-    """tta.py:119-136"""
-
-    def __init__(self, ttas, merge_func=merge_detections):
-        super().__init__(ttas)
-        self.merge_func = merge_func
-
-    def pre_process(self, x):
-        return sum([tta.pre_process(x) for tta in self], [])
-
-    def post_process(self, y):
-        l = len(y) // len(self)
-        Y = [tta.post_process(y[i * l:i * l + l]) for i, tta in enumerate(self)]
-        return [[[self.merge_func(b) for b in zip(*ci)] for ci in zip(*yi)] for yi in zip(*Y)]
+def apply_plan(x, plan):
+    """Image side of the plan on a (B, 3, H, W) tensor: bilinear resize (align_corners False) / flips (tta.py:147-190)."""
+    for op in plan:
+        if op[0] == 'resize':
+            x = torch.nn.functional.interpolate(x, scale_factor=op[1], mode='bilinear', align_corners=False)
+        else:
+            x = torch.flip(x, [3] if op[0] == 'hflip' else [2])
+    return x
 
 
-class OrigTTA(OpTTA):
-    def pre_process(self, x):
-        return x
-
-    def post_process(self, y):
-        return y
-
-
-class HFlipTTA(OpTTA):
-    """tta.py:147-156"""
-
-    def pre_process(self, x):
-        return [torch.flip(xi, [3]) for xi in x]
-
-    def post_process(self, y):
-        for yi in y:
-            for d in yi:
-                for c in d:
-                    c[..., 1] = 1 - c[..., 1]
-        return y
-
-
-class VFlipTTA(OpTTA):
-    def pre_process(self, x):
-        return [torch.flip(xi, [2]) for xi in x]
-
-    def post_process(self, y):
-        for yi in y:
-            for d in yi:
-                for c in d:
-                    c[..., 2] = 1 - c[..., 2]
-        return y
-
-
-class ResizeTTA(OpTTA):
-    """tta.py:179-190"""
-
-    def __init__(self, scale_factor):
-        self.scale_factor = scale_factor
-
-    def __repr__(self):
-        return self.__class__.__name__ + f'(scale_factor={self.scale_factor})'
-
-    def pre_process(self, x):
-        return [torch.nn.functional.interpolate(xi, scale_factor=self.scale_factor, mode='bilinear', align_corners=False)
-                for xi in x]
-
-    def post_process(self, y):
-        return y
+def undo_plan(detections, plan):
+    """Box side: detections = [per image [per class ndarray (n, 5) [score, cx, cy, w, h] normalised]].  Boxes are normalised,
+    so a resize needs no undo; a horizontal / vertical flip mirrors cx / cy (tta.py:150-155,167-172), in reverse plan order."""
+    for op in reversed(plan):
+        col = {'hflip': 1, 'vflip': 2}.get(op[0])
+        if col is None:
+            continue
+        for per_class in detections:
+            for boxes in per_class:
+                boxes[..., col] = 1 - boxes[..., col]
+    return detections
 
 
 class TTA(nn.Module):
-    """tta.py:228-267 (orig / xS / hflip / vflip; the unused brute / dflip / batch modes are not provided)."""
+    """tta.py:228-267: detector.predict on the augmented image, detections mapped back."""
 
     def __init__(self, detector, data_aug):
         super().__init__()
         self.detector = detector
-        ttas = []
-        if 'orig' in data_aug:
-            ttas.append(OrigTTA())
-        for aug in data_aug:
-            if aug.startswith('x'):
-                ttas.append(ResizeTTA(float(aug[1:])))
-        for unsupported in ('brute', 'dflip', 'batch'):
-            if unsupported in data_aug:
-                raise NotImplementedError('TTA mode %r is not part of the Waymo hot path' % unsupported)
-        if 'hflip' in data_aug:
-            ttas.append(HFlipTTA())
-        if 'vflip' in data_aug:
-            ttas.append(VFlipTTA())
-        self.tta = SequentialTTA(ttas)
+        self.plan = parse_tta(list(data_aug))
 
     def _fused_pre(self):
-        """(scale, hflip, vflip) when the sequence is resize / flips only (the Waymo setting --tta x1.5,hflip) and the
-        detector can fold them into its pre-processing kernel; None otherwise."""
-        scale, hflip, vflip = 1.0, False, False
-        for t in self.tta:
-            if isinstance(t, OrigTTA):
-                continue
-            if isinstance(t, ResizeTTA) and not (hflip or vflip):     # resize must come before the flips to commute
-                scale *= float(t.scale_factor)
-            elif isinstance(t, HFlipTTA):
-                hflip = not hflip
-            elif isinstance(t, VFlipTTA):
-                vflip = not vflip
-            else:
-                return None
-        n_resize = sum(isinstance(t, ResizeTTA) for t in self.tta)
-        return (scale, hflip, vflip) if n_resize <= 1 else None
+        """(scale, hflip, vflip) when the plan is at most one resize followed by flips (the Waymo setting --tta x1.5,hflip), which
+        the detector folds into its pre-processing kernel; None otherwise."""
+        if sum(op[0] == 'resize' for op in self.plan) > 1:
+            return None
+        scale = next((op[1] for op in self.plan if op[0] == 'resize'), 1.0)
+        return float(scale), ('hflip',) in self.plan, ('vflip',) in self.plan
 
     def predict(self, x):
         fused = self._fused_pre() if hasattr(self.detector, 'predict_device') and torch.is_tensor(x) else None
         if fused is not None:
             # one HIP kernel: resize + flip + BGR + normalise + pad (tta.py:147-190 folded into the detector input)
-            Y = [self.detector.predict(x, *fused)]
+            y = self.detector.predict(x, *fused)
         else:
-            X = self.tta.pre_process([x])
-            Y = [self.detector.predict(xi) for xi in X]
-        y = self.tta.post_process(Y)
-        return y[0]
+            y = self.detector.predict(apply_plan(x, self.plan))
+        return undo_plan(y, self.plan)

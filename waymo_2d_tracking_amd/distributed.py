@@ -58,6 +58,55 @@ def gather_object_rank0(obj):
     return out
 
 
+def _device():
+    import torch.distributed as dist
+    return 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+
+
+def gather_columns_rank0(columns):
+    """Variable-length gather of a dict of equally long 1-D / 2-D arrays (a columnar row set) to rank 0.
+
+    One all_gather of the row counts + ONE padded tensor gather: every rank serialises its columns into a single byte
+    buffer (the column names / dtypes / trailing shapes are the same on all ranks, only the row count differs), the buffers
+    are padded to the longest one and gathered to rank 0 - over RCCL / xGMI when the backend is "nccl" (device tensors), gloo
+    in the CPU tests.  Returns the concatenated columns (rank order) on rank 0, None elsewhere.  No pickling."""
+    w, r = world()
+    names = sorted(columns)
+    cols = {k: np.ascontiguousarray(columns[k]) for k in names}
+    n = len(cols[names[0]]) if names else 0
+    assert all(len(cols[k]) == n for k in names), 'columns must have the same number of rows'
+    if w == 1:
+        return cols
+    import torch
+    import torch.distributed as dist
+    counts = all_gather_int(n)
+    row_bytes = [cols[k].dtype.itemsize * int(np.prod(cols[k].shape[1:], dtype=np.int64)) for k in names]
+    max_rows = max(counts)
+    dev = _device()
+    buf = np.zeros(max_rows * sum(row_bytes), dtype=np.uint8)
+    o = 0
+    for k, rb in zip(names, row_bytes):                        # column-major inside the buffer: [col0 rows | col1 rows | ...]
+        b = cols[k].reshape(-1).view(np.uint8)
+        buf[o:o + b.size] = b
+        o += max_rows * rb
+    t = torch.from_numpy(buf).to(dev)
+    if r == 0:
+        parts = [torch.empty_like(t) for _ in range(w)]
+        dist.gather(t, parts, dst=0)
+    else:
+        dist.gather(t, None, dst=0)
+        return None
+    out = {k: [] for k in names}
+    for rank, part in enumerate(parts):
+        raw = part.cpu().numpy()
+        o = 0
+        for k, rb in zip(names, row_bytes):
+            seg = raw[o:o + counts[rank] * rb]
+            out[k].append(seg.view(cols[k].dtype).reshape((counts[rank],) + cols[k].shape[1:]))
+            o += max_rows * rb
+    return {k: np.concatenate(v) for k, v in out.items()}
+
+
 def all_gather_int(value):
     w, r = world()
     if w == 1:
@@ -71,26 +120,37 @@ def all_gather_int(value):
     return [int(o.item()) for o in outs]
 
 
-def track_all_sharded(predictions, iou_thresholds, max_age, min_hits, segment_ids=None, track_fn=None, id_start=0):
-    """Distributed twin of tracking.utils.track_all: every rank tracks its block of streams, rank 0 receives the
-    full list of tracking-JSON rows in the reference's order with the reference's global IDs (None on other ranks).
-    track_fn(packed, iou_thresholds, max_age, min_hits, score_threshold, id_base) -> (out dict, births); default =
-    the HIP path (tracking.utils.track_packed)."""
+def track_packed_sharded(packed, iou_thresholds, max_age, min_hits, score_threshold=None, track_fn=None, id_start=0):
+    """Sharded tracking of a packed set of streams (tracking.utils.pack_streams / NativeDetFile.packed layout, identical on
+    every rank): each rank tracks its contiguous block of streams (balanced by frame count), the per-rank birth counts are
+    all_gathered (the one exchange step: ids of rank r start after the births of ranks < r, sort.py:86) and the result COLUMNS
+    (frame index into the full packed set, category, bbox, score, object id) travel to rank 0 in one tensor gather.
+    Returns (columns or None, total births)."""
     from .tracking import utils as T
     if track_fn is None:
         track_fn = T.track_packed
     w, r = world()
-    keys = [(s, c) for s in predictions if (segment_ids is None or s in segment_ids) for c in predictions[s]]
-    counts = [len(predictions[s][c]) for s, c in keys]
-    lo, hi = balanced_stream_split(counts, w)[r]
-    packed = T.pack_streams(predictions, keys[lo:hi])
-    out, births = track_fn(packed, iou_thresholds, max_age, min_hits, None, 0)
+    so = np.asarray(packed['stream_frame_offsets'])
+    lo, hi = balanced_stream_split(np.diff(so), w)[r]
+    mine = T.slice_streams(packed, lo, hi)
+    out, births = track_fn(mine, iou_thresholds, max_age, min_hits, score_threshold, 0)
     all_births = all_gather_int(births)                        # the one exchange step of the path
     offset = id_start + sum(all_births[:r])
-    out = dict(out)
-    out['object_id'] = out['object_id'] + offset
-    rows = T.format_tracks(packed, out)
-    gathered = gather_object_rank0(rows)
-    if r != 0:
-        return None, sum(all_births)
-    return [row for part in gathered for row in part], sum(all_births)
+    cols = dict(frame=np.asarray(out['frame'], np.int64) + int(so[lo]), category=np.asarray(out['category'], np.int32),
+                bbox=np.asarray(out['bbox'], np.float64).reshape(-1, 4), score=np.asarray(out['score'], np.float64),
+                object_id=np.asarray(out['object_id'], np.int64) + offset)
+    return gather_columns_rank0(cols), sum(all_births)
+
+
+def track_all_sharded(predictions, iou_thresholds, max_age, min_hits, segment_ids=None, track_fn=None, id_start=0):
+    """Distributed twin of tracking.utils.track_all: rank 0 receives the full list of tracking-JSON rows in the reference's
+    order with the reference's global IDs (None on other ranks).
+    track_fn(packed, iou_thresholds, max_age, min_hits, score_threshold, id_base) -> (out dict, births); default =
+    the HIP path (tracking.utils.track_packed)."""
+    from .tracking import utils as T
+    keys = [(s, c) for s in predictions if (segment_ids is None or s in segment_ids) for c in predictions[s]]
+    packed = T.pack_streams(predictions, keys)
+    cols, births = track_packed_sharded(packed, iou_thresholds, max_age, min_hits, None, track_fn, id_start)
+    if cols is None:
+        return None, births
+    return T.format_tracks(packed, cols), births

@@ -55,38 +55,60 @@ def main_native(args):
     return 0
 
 
+def main_sharded(args, world, rank):
+    """torchrun: one process per GPU.  Every rank parses the file natively, tracks its block of streams and the result
+    columns reach rank 0 through one tensor gather (distributed.track_packed_sharded); rank 0 writes the JSON natively."""
+    import torch
+    import torch.distributed as dist
+    from . import utils as T
+    from ..distributed import track_packed_sharded
+    backend = os.environ.get('WT_DIST_BACKEND', 'nccl')
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    dist.init_process_group(backend)
+    nat = T.NativeDetFile(args.input, args.score_threshold)
+    packed = nat.packed()
+    if args.segment_id:
+        keep = [i for i, (s, _) in enumerate(packed['stream_keys']) if s == args.segment_id]
+        packed = T.slice_streams(packed, keep[0], keep[-1] + 1) if keep else T.slice_streams(packed, 0, 0)
+    start_time = time.time()
+    if rank == 0:
+        for segment_id in dict.fromkeys(s for s, _ in packed['stream_keys']):
+            print(segment_id)
+    cols, births = track_packed_sharded(packed, args.iou_threshold, args.max_age, args.min_hits, None, None, T._GLOBAL_IDS['next'])
+    T._GLOBAL_IDS['next'] += births
+    if rank == 0:
+        print("duration: %.2fs" % (time.time() - start_time))
+        if args.segment_id:
+            with open(args.output, 'wt') as fp:
+                json.dump(T.format_tracks(packed, cols), fp)
+        else:
+            nat.write_tracks(args.output, cols)
+    nat.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     print(args)
-    if not args.python_io and not args.segment_id and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        return main_sharded(args, world, rank)
+    if not args.python_io and not args.segment_id:
         return main_native(args)
     predictions = read_data_file(args.input, args.score_threshold)
     if args.segment_id:
         predictions = {k: v for k, v in predictions.items() if k in [args.segment_id]}
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    if world > 1:                                  # torchrun: one process per GPU, streams sharded (distributed.py)
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl')
     start_time = time.time()
-    if rank == 0:
-        for segment_id in predictions.keys():
-            print(segment_id)
-    if world > 1:
-        from ..distributed import track_all_sharded
-        tracked_predictions, _ = track_all_sharded(predictions, args.iou_threshold, args.max_age, args.min_hits)
-    else:
-        tracked_predictions = track_all(predictions, args.iou_threshold, args.max_age, args.min_hits)
-    if rank == 0:
-        print("duration: %.2fs" % (time.time() - start_time))
-        with open(args.output, 'wt') as fp:
-            json.dump(tracked_predictions, fp)
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    for segment_id in predictions.keys():
+        print(segment_id)
+    tracked_predictions = track_all(predictions, args.iou_threshold, args.max_age, args.min_hits)
+    print("duration: %.2fs" % (time.time() - start_time))
+    with open(args.output, 'wt') as fp:
+        json.dump(tracked_predictions, fp)
     return 0
 
 

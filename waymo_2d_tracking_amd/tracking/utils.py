@@ -95,6 +95,23 @@ def pack_streams(predictions, stream_keys=None):
         stream_keys=list(stream_keys))
 
 
+def slice_streams(packed, lo, hi):
+    """Streams [lo, hi) of a packed set as a packed set of their own (CSR offsets rebased) - the shard of one rank."""
+    so = np.asarray(packed['stream_frame_offsets'])
+    fo = np.asarray(packed['frame_det_offsets'])
+    f0, f1 = int(so[lo]), int(so[hi])
+    d0, d1 = int(fo[f0]), int(fo[f1])
+    out = {k: np.ascontiguousarray(packed[k][d0:d1]) for k in ('x', 'y', 'w', 'h', 'score', 'category')}
+    out['frame_det_offsets'] = np.ascontiguousarray(fo[f0:f1 + 1] - d0)
+    out['stream_frame_offsets'] = np.ascontiguousarray(so[lo:hi + 1] - f0)
+    out['frame_ids'] = np.ascontiguousarray(packed['frame_ids'][f0:f1]) if 'frame_ids' in packed else None
+    out['clip_w'] = np.ascontiguousarray(packed['clip_w'][lo:hi])
+    out['clip_h'] = np.ascontiguousarray(packed['clip_h'][lo:hi])
+    if 'stream_keys' in packed:
+        out['stream_keys'] = list(packed['stream_keys'][lo:hi])
+    return out
+
+
 def make_params(max_age, min_hits, score_threshold, iou_threshold):
     """wt_track_params + the arrays that must stay alive while it is used."""
     n_classes = len(iou_threshold)
