@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument('--k-inputs', type=int, default=13)
     ap.add_argument('--frames-per-step', type=int, default=10, help='e2e/detect: frames per step (multiple of 5)')
     ap.add_argument('--tta', default='', help="e2e/detect: test-time augmentation of the detector pass, e.g. x1.5,hflip (config 4)")
+    ap.add_argument('--collate', action='store_true',
+                    help='e2e: gather every chunk\'s track rows to rank 0 inside the timed region (the submission collation over RCCL)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-verify', action='store_true', help='skip the oracle replay of the timed output (after the timed region)')
     return ap.parse_args()

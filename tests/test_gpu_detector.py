@@ -158,24 +158,74 @@ def test_full_size_frame_properties():
     assert torch.allclose(score * 1e5, torch.round(score * 1e5), atol=1e-6)
 
 
+def _random_model_file(tmp_path, seed=0):
+    """A {args, kwargs, state_dict} model file in the reference's format (random weights)."""
+    from waymo_2d_tracking_amd.detnet import nn as detnn
+    net = detnn.create('detectron2:Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml',
+                       ['vehicle', 'pedestrian', 'sign', 'cyclist'], pretrained=None, freeze_pretrained=2, frozen_bn=True, seed=seed)
+    path = tmp_path / 'random.model'
+    net.save(str(path))
+    return str(path)
+
+
 def test_inference_cli_on_image_folder(tmp_path):
-    """inference.py drop-in: image folder -> detection JSON (coco.py:229-252 rows) == predict + load_prediction."""
-    from PIL import Image
+    """inference.py drop-in: image folder -> detection JSON (coco.py:229-252 rows) == predict + load_prediction; -o writes the
+    prediction store, --resume skips the tested samples and merges, --auto-contrast changes the input like PIL does."""
+    import json
+    from PIL import Image, ImageOps
     from waymo_2d_tracking_amd.detnet import inference as I
+    from waymo_2d_tracking_amd.detnet.trainer import Predictions
     rng = np.random.default_rng(0)
     root = tmp_path / 'images'
-    for seg, ts, cam in (('segA', 100, 'FRONT'), ('segA', 200, 'FRONT'), ('segB', 100, 'SIDE_LEFT')):
+    names = (('segA', 100, 'FRONT'), ('segA', 200, 'FRONT'), ('segB', 100, 'SIDE_LEFT'), ('segB', 200, 'SIDE_LEFT'))
+    for seg, ts, cam in names:
         d = root / seg / str(ts)
         d.mkdir(parents=True, exist_ok=True)
-        Image.fromarray(rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)).save(d / (cam + '.png'))
+        Image.fromarray(rng.integers(30, 200, (96, 160, 3), dtype=np.uint8)).save(d / (cam + '.png'))
+    model = _random_model_file(tmp_path)
     out = tmp_path / 'sub.json'
-    I.main(['-i', str(root), '--export', str(out), '--batch-size=1', '--tta', 'x1.5,hflip'])
-    import json
+    rows0 = I.main(['-m', model, '-i', str(root), '--export', str(out), '--batch-size=1', '--tta', 'x1.5,hflip', '-o', str(tmp_path / 'o')])
     rows = json.load(open(out))
-    assert len(rows) > 0
+    assert len(rows) > 0 and len(rows) == len(rows0['image'])
     ids = {r['image_id'] for r in rows}
-    assert ids <= {'segA/100/FRONT', 'segA/200/FRONT', 'segB/100/SIDE_LEFT'}
+    assert ids <= {'%s/%d/%s' % n for n in names}
     for r in rows:
         assert set(r) == {'image_id', 'category_id', 'bbox', 'score'}
         assert all(isinstance(v, int) for v in r['bbox']) and 1 <= r['category_id'] <= 4
         assert round(r['score'], 5) == r['score']
+    # the exported rows == Detectron2Det.predict + load_prediction (the reference's dict path) on the same files
+    from waymo_2d_tracking_amd.detnet import nn as detnn
+    from waymo_2d_tracking_amd.detnet.nn.tta import TTA
+    net = detnn.load(model).cuda().eval()
+    sizes, preds = {}, {}
+    for image_id, path in I.list_images(str(root)):
+        img = Image.open(path).convert('RGB')
+        x = torch.as_tensor(np.asarray(img, dtype=np.float32).transpose(2, 0, 1)).unsqueeze(0).cuda()
+        preds[image_id] = TTA(net, ['x1.5', 'hflip']).predict(x)[0]
+        sizes[image_id] = (img.width, img.height)
+    ref_rows = I.load_prediction(sizes, net.classnames, preds)
+    assert [(r['image_id'], r['category_id'], r['bbox']) for r in rows] == [(r['image_id'], r['category_id'], r['bbox']) for r in ref_rows]
+    # -o wrote the store; --resume on a store that holds two of the four images detects only the others and merges
+    store = Predictions.open(tmp_path / 'o')
+    assert len(store) == 4
+    part = Predictions(store.classnames, store.image_ids)
+    for k in list(store.keys())[:2]:
+        part[k] = store[k]
+    part.save(tmp_path / 'part' / 'detections.pkl')
+    out2 = tmp_path / 'sub2.json'
+    I.main(['-m', model, '-i', str(root), '--export', str(out2), '--tta', 'x1.5,hflip', '--resume', str(tmp_path / 'part')])
+    assert json.load(open(out2)) == rows
+    # --auto-contrast = ImageOps.autocontrast, bit for bit
+    img = Image.open(I.list_images(str(root))[0][1]).convert('RGB')
+    got = I.autocontrast_(torch.from_numpy(np.asarray(img)).cuda()).cpu().numpy()
+    assert np.array_equal(got, np.asarray(ImageOps.autocontrast(img)))
+    flat = Image.fromarray(np.full((8, 8, 3), 77, np.uint8))
+    assert np.array_equal(I.autocontrast_(torch.from_numpy(np.asarray(flat)).cuda()).cpu().numpy(), np.asarray(ImageOps.autocontrast(flat)))
+    out3 = tmp_path / 'sub3.json'
+    I.main(['-m', model, '-i', str(root), '--export', str(out3), '--auto-contrast=1'])
+    assert json.load(open(out3)) != json.load(open(out))
+    # unsupported flags fail loudly; no output target is an error like in the reference
+    with pytest.raises(NotImplementedError):
+        I.main(['-m', model, '-i', str(root), '--export', str(out3), '--clahe=1'])
+    with pytest.raises(UserWarning):
+        I.main(['-m', model, '-i', str(root)])

@@ -20,7 +20,7 @@ for k, d in acc.items():
     rd = (m['TCC_EA0_RDREQ_sum'] - m['TCC_EA0_RDREQ_32B_sum']) * 64 + m['TCC_EA0_RDREQ_32B_sum'] * 32
     wr = m['TCC_EA0_WRREQ_64B_sum'] * 64 + (m['TCC_EA0_WRREQ_sum'] - m['TCC_EA0_WRREQ_64B_sum']) * 32
     out[k] = dict(launches=len(d['TCC_EA0_RDREQ_sum']), counters=m, fetch_bytes_raw=rd,
-                  fetch_bytes_gfx950_corrected=2 * rd, write_bytes=wr)
+                  fetch_bytes_gfx950_corrected=2 * rd, write_bytes=wr, traffic_bytes_per_launch=2 * rd + wr)
 json.dump(out, open(sys.argv[2], 'w'), indent=1, sort_keys=True)
 print(json.dumps(out))
 PY

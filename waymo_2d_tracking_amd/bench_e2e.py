@@ -148,6 +148,20 @@ class DetectTrackPipeline(object):
         self.n_dets_last = total
         return total
 
+    def collate_last_chunk(self):
+        """Optional timed leg (bench.py --collate): the rows of the chunk tracked LAST step travel to rank 0 the way the CLIs
+        collate a submission (distributed.gather_columns_rank0: counts all_gather + one padded tensor gather over RCCL).  The
+        previous chunk is used so that the gather overlaps the SORT of the current one."""
+        from . import distributed as D
+        c = self.chunk - 2
+        if c < 0:
+            return None
+        k = int(self.chunk_counts[c, 0].item())
+        cols = dict(frame=self.out_frame[c, :k].cpu().numpy(), category=self.out_cat[c, :k].cpu().numpy(),
+                    bbox=self.out_bbox[c, :k].cpu().numpy(), score=self.out_score[c, :k].cpu().numpy(),
+                    local_id=self.out_id[c, :k].cpu().numpy())
+        return D.gather_columns_rank0(cols)
+
     def history(self):
         """Synchronise and return what the trackers of the CURRENT segment consumed and produced so far:
         (packed, rows) - `packed` is the pack_streams() layout of the detections (streams = cameras, frames of all chunks
@@ -237,6 +251,10 @@ def run(args, world, rank, timed_steps):
             ops.EVENT_LOG = []
         state['n'] += 1
         pipe.step(track)
+        if track and getattr(args, 'collate', False):
+            got = pipe.collate_last_chunk()
+            if got is not None:
+                state['collated_rows'] = state.get('collated_rows', 0) + len(got['frame'])
 
     dt, ev_ms = timed_steps(world, step, steps, warmup)
     log, ops.EVENT_LOG = ops.EVENT_LOG or [], None
@@ -267,7 +285,8 @@ def run(args, world, rank, timed_steps):
                         % (', --tta ' + args.tta if getattr(args, 'tta', '') else '',
                            'SORT (max_age 2, min_hits 0, all boxes tracked; trackers resident for the whole segment)' if track else 'no tracking', 5, fps),
                roofline=roofline,
-               extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births))
+               extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births,
+                          collated_rows_rank0=state.get('collated_rows')))
     res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters
     return res, steps, warmup
 

@@ -9,6 +9,7 @@
 // current slab; bias / residual / ReLU are fused in the epilogue.
 #include "common.h"
 #include "../../include/waymodet.h"
+#include <cstdlib>
 
 namespace {
 
@@ -150,9 +151,13 @@ extern "C" int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias
         const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
         // few tiles and a long K (the box-head FC: 256 tiles, K = 12544): split K so that >= 2 workgroups share a CU and
         // hide each other's LDS latency; partial sums meet in C through f32 atomics, the epilogue runs as a second pass
+        // Run-to-run determinism: with TWO slices the result 0 + a + b is the same in either arrival order (f32 addition is
+        // commutative), with more slices the atomic order would matter - so the split is capped at 2 unless
+        // WD_GEMM_SPLITK_MAX (experiments) raises it.
+        static const int splitk_max = []() { const char* e = getenv("WD_GEMM_SPLITK_MAX"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
         int splitk = 1;
         if (!residual && (N % 4) == 0 && K >= 2048) {
-            while (tiles * splitk < 512 && splitk < 8 && K / (splitk * 2) >= 1024) splitk *= 2;
+            while (tiles * splitk < 512 && splitk * 2 <= splitk_max && K / (splitk * 2) >= 1024) splitk *= 2;
         }
         if (splitk > 1) WT_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, stream));
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2>), dim3((unsigned)(tiles * splitk)), dim3(256), 0, stream, A, Bt, bias, residual,

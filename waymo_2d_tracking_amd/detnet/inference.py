@@ -1,15 +1,19 @@
 """Detection inference CLI - mirrors /root/reference/inference.py + /root/reference/detnet/inference.py
-(flags :26-60, PredictModel :77-130, inference() :151-199) and the JSON export
-(/root/reference/detnet/export.py:159-165 -> /root/reference/detnet/data/coco.py:229-252).
+(flags :26-60, PredictModel :77-130, inference() :151-199), the test driver (/root/reference/detnet/trainer/test.py:189-279:
+`-j N`, `--resume`, `-o`) and the JSON export (/root/reference/detnet/export.py:159-165 -> detnet/data/coco.py:229-252).
 
-    python -m waymo_2d_tracking_amd.detnet.inference -m detectron2:Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml \
-        -i IMAGES_DIR --export submission.json [--tta x1.5,hflip] [--batch-size 1]
-    torchrun --nproc-per-node 8 -m waymo_2d_tracking_amd.detnet.inference ...     # one process per GPU
+    python -m waymo_2d_tracking_amd.detnet.inference -m MODEL_FILE -i IMAGES_DIR --export submission.json \
+        [--tta x1.5,hflip] [--auto-contrast=1] [-j 8] [-o OUT_DIR] [--resume OUT_DIR/detections.pkl] [--eval --annotations GT.json]
+    torchrun --nproc-per-node 8 -m waymo_2d_tracking_amd.detnet.inference ...     # the same, started by torchrun
 
-Multi-GPU: the reference spawns `-j N` processes with contiguous dataset shards and merges shelve files
-(detnet/trainer/test.py:227-270); here torchrun starts one process per GPU, each takes its contiguous shard
-(distributed.contiguous_split) and rank 0 receives the rows through one gather (RCCL) - no files, no collective
-inside the detection loop.
+MODEL_FILE is a `{args, kwargs, state_dict}` file of the reference or of this package (nn/__init__.py); the string
+`detectron2:<yaml>` loads the detectron2 COCO checkpoint like the reference does (it must be available locally).
+
+Multi-GPU: the reference spawns `-j N` processes with contiguous dataset shards and merges per-process shelve files
+(trainer/test.py:227-270).  Here `-j N` spawns N processes (one per GPU) - or torchrun does - each takes its contiguous shard
+(distributed.contiguous_split), fills a columnar prediction store (trainer/predictions.py) and rank 0 receives all rows in one
+tensor gather over RCCL - no files, no collective inside the detection loop.  Image decoding (PIL, like the reference's
+dataset workers) runs in a thread pool ahead of the GPU; AutoContrast runs on the GPU.
 """
 import argparse
 import json
@@ -30,7 +34,7 @@ def arg2bool(v):
 
 
 def add_test_argument(parser):
-    """detnet/inference.py:26-46 (flags that do not apply to the Cascade R-CNN path are accepted and ignored)."""
+    """detnet/inference.py:26-46; flags this path cannot honour raise in check_supported()."""
     parser.add_argument('--device', default='auto', choices=['auto', 'cuda', 'cpu', 'half'])
     parser.add_argument("-m", "--model", type=str, default='detectron2:Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml',
                         help='pre/trained model file')
@@ -54,7 +58,8 @@ def build_parser():
     parser.add_argument("-i", "--input", type=str, help='root directory of input images')
     parser.add_argument("-o", "--output", type=str, help='root directory of output')
     parser.add_argument("--exclusive", type=str)
-    parser.add_argument('-j', '--jobs', type=int, default=1, help='accepted for compatibility; use torchrun for N GPUs')
+    parser.add_argument('-j', '--jobs', type=int, default=1, help='number of processes = GPUs (one process per GPU)')
+    parser.add_argument('--annotations', type=str, help='COCO-format ground truth for --eval')
     parser.add_argument('--resume', type=str)
     parser.add_argument('--eval', action='store_true')
     parser.add_argument('--export', type=str, help='path of export file')
@@ -96,7 +101,7 @@ class PredictModel(torch.nn.Module):
 def load_prediction(image_sizes, classnames, predictions, category_ids=None):
     """COCODetection.load_prediction (detnet/data/coco.py:229-252): normalised per-class [score,cx,cy,w,h] ->
     [{image_id, category_id, bbox [int x, y, w, h], score (5 decimals)}].  category ids default to 1..C
-    (waymo_to_coco.py:19,36)."""
+    (waymo_to_coco.py:19,36).  Dict form of export.detection_rows (kept for API parity)."""
     results = []
     for image_id, (width, height) in image_sizes.items():
         det = predictions[str(image_id)]
@@ -117,59 +122,206 @@ def list_images(root):
     return [(str(p.relative_to(root).with_suffix('')), p) for p in files]       # image_id = "<segment>/<ts>/<CAMERA>"
 
 
-def inference(args):
-    """detnet/inference.py:151-199 for an image folder."""
-    from PIL import Image
+def autocontrast_(img_u8):
+    """ImageOps.autocontrast(image) of PIL (cutoff 0; the reference's AutoContrast transform, trainer/transforms/vision.py:
+    1069-1075) on a (H, W, 3) uint8 DEVICE tensor: per channel lo / hi = darkest / brightest value present; if hi <= lo the
+    channel is unchanged, else lut[v] = clamp(int(v * 255 / (hi - lo) - lo * 255 / (hi - lo)), 0, 255).  Bit-exact with PIL
+    (tests/test_gpu_detector.py); float64 like PIL's Python arithmetic."""
+    flat = img_u8.reshape(-1, img_u8.shape[-1])
+    lo = flat.amin(0).double()
+    hi = flat.amax(0).double()
+    v = torch.arange(256, dtype=torch.float64, device=img_u8.device).unsqueeze(1)
+    span = torch.where(hi > lo, hi - lo, torch.ones_like(hi))
+    scale = 255.0 / span
+    lut = torch.trunc(v * scale + (-lo * scale)).clamp_(0, 255)
+    lut = torch.where((hi > lo).unsqueeze(0), lut, v.expand(-1, lut.shape[1])).to(torch.uint8)      # (256, C)
+    out = torch.gather(lut, 0, flat.long())
+    return out.reshape(img_u8.shape)
+
+
+def resize_size(w, h, size, max_size=None):
+    """Resize.compute_scaled_image_size (trainer/transforms/vision.py:168-190) for an int size: (out_h, out_w)."""
+    if (w <= h and w == size) or (h <= w and h == size):
+        return h, w
+    if w < h:
+        ow, oh = size, int(size * h / w)
+    else:
+        oh, ow = size, int(size * w / h)
+    if max_size:
+        if oh > max_size:
+            ow, oh = int(max_size / oh * ow), max_size
+        if ow > max_size:
+            oh, ow = int(max_size / ow * oh), max_size
+    return oh, ow
+
+
+class ImageLoader(object):
+    """Decode ahead of the GPU: PIL decode + ToRGB (+ Resize, PIL bilinear like the reference) in a thread pool, pinned
+    staging buffer, asynchronous H2D of the uint8 HWC image (7.4 MB per 1920x1280 frame).  Yields
+    (image_id, device uint8 (H, W, 3), (width, height) of the image handed to the detector)."""
+
+    def __init__(self, items, resize=None, max_image_size=None, workers=4, depth=4):
+        self.items, self.resize, self.max_size = items, resize, max_image_size
+        self.workers, self.depth = workers, depth
+
+    def _decode(self, path):
+        from PIL import Image
+        img = Image.open(path).convert('RGB')                                       # ToRGB (vision.py:954)
+        if self.resize:
+            oh, ow = resize_size(img.width, img.height, int(self.resize), self.max_size)
+            img = img.resize((ow, oh), Image.BILINEAR)
+        return np.asarray(img, dtype=np.uint8)
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(self.workers) as pool:
+            pending = []
+            it = iter(self.items)
+            for image_id, path in it:
+                pending.append((image_id, pool.submit(self._decode, path)))
+                if len(pending) >= self.depth:
+                    break
+            while pending:
+                image_id, fut = pending.pop(0)
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append((nxt[0], pool.submit(self._decode, nxt[1])))
+                arr = fut.result()
+                t = torch.from_numpy(arr).pin_memory().cuda(non_blocking=True)
+                yield image_id, t, (arr.shape[1], arr.shape[0])
+
+
+def check_supported(args):
+    """Flags of the reference that this path cannot honour fail loudly instead of being ignored."""
+    if args.clahe:
+        raise NotImplementedError('--clahe needs scikit-image equalize_adapthist (vision.py:1088-1092), which is not available')
+    if args.device in ('cpu', 'half'):
+        raise NotImplementedError('--device %s: the detector runs in fp32 on the GPU only (HIP kernels, no CPU fallback)' % args.device)
+    if args.soft_nms or args.bbox_voting:
+        raise NotImplementedError('--soft-nms / --bbox-voting belong to the SSD detect layer of the reference, not to Cascade R-CNN')
+    if args.resize is not None:
+        try:
+            int(args.resize)
+        except ValueError:
+            raise NotImplementedError('--resize takes the length of the shorter edge (int); (h, w) pairs are not supported')
+    if args.eval and not args.annotations:
+        raise ValueError('--eval needs --annotations GT.json (COCO-format ground truth; the reference reads it from --data-root)')
+    if args.export_format != 'json':
+        raise NotImplementedError('--export-format json only')
+
+
+def run_rank(args, world, rank):
+    """One process = one GPU: detect the shard, collate, and on rank 0 save / evaluate / export."""
     from . import nn as detnn
+    from .trainer import Predictions
     from .. import distributed as D
     torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
     if args.cudnn_benchmark:
         from ..tuning import enable_gemm_tuning
         enable_gemm_tuning()                       # library-GEMM counterpart of --cudnn-benchmark
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise RuntimeError('the detector runs on the GPU only (HIP kernels, no CPU fallback)')
-    torch.cuda.set_device(local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     start = time.time()
     model = detnn.load(args.model).cuda().eval()
     tta = [t for t in args.tta.split(',') if t] if args.tta else None
     predict = PredictModel(model, dict(tta=tta, max_bbox=args.max_bbox))
     images = list_images(args.input)
+    if args.exclusive:
+        images = [(i, p) for i, p in images if args.exclusive not in i]
+    image_ids = [i for i, _ in images]
+    resumed = None
+    if args.resume:                                # trainer/test.py:190-195: skip the samples already tested
+        resumed = Predictions.open(args.resume)
+        done = set(resumed.keys())
+        if rank == 0:
+            print(f"resuming {len(done)} tested samples")
+        images = [(i, p) for i, p in images if i not in done]
     lo, hi = D.contiguous_split(len(images), world)[rank]
-    sizes, preds = {}, {}
+    store = Predictions(model.classnames, image_ids)
+    sizes = np.zeros((len(image_ids), 2), np.int32)
+    index = {k: i for i, k in enumerate(image_ids)}
     with torch.no_grad():
-        for image_id, path in images[lo:hi]:
-            img = Image.open(path).convert('RGB')                                   # ToRGB
-            x = torch.as_tensor(np.asarray(img, dtype=np.float32).transpose(2, 0, 1)).unsqueeze(0)   # ToTensor(scaling=False)
-            preds[image_id] = predict(x.cuda())[0]
-            sizes[image_id] = (img.width, img.height)
-    rows = load_prediction(sizes, model.classnames, preds)
-    gathered = D.gather_object_rank0(rows)
+        for image_id, img, (w, h) in ImageLoader(images[lo:hi], args.resize, args.max_image_size):
+            if args.auto_contrast:
+                img = autocontrast_(img)
+            store[image_id] = predict(img.unsqueeze(0))[0]            # uint8 HWC -> fused pre-processing kernel
+            sizes[index[image_id]] = (w, h)
+    cols, tested = store.shard_columns()
+    allc = D.gather_columns_rank0(cols)                               # the one exchange: result rows -> rank 0
+    meta = D.gather_columns_rank0(dict(image=np.nonzero(tested)[0].astype(np.int32), size=sizes[tested]))
+    rows = None
     if rank == 0:
-        rows = [r for part in gathered for r in part]
+        mask = np.zeros(len(image_ids), bool)
+        mask[meta['image']] = True
+        sizes[meta['image']] = meta['size']
+        predictions = Predictions.from_shards(model.classnames, image_ids, [allc], [mask])
+        if resumed is not None:
+            predictions.update(resumed)
+        if args.output:                                              # trainer/test.py:272-276
+            out_dir = Path(args.output)
+            out_dir.mkdir(parents=True, exist_ok=True)
+            print('saving', out_dir / 'detections.pkl')
+            predictions.save(out_dir / 'detections.pkl')
+        image_sizes = {k: tuple(int(v) for v in sizes[i]) for i, k in enumerate(image_ids) if predictions.tested[i] and sizes[i, 0] > 0}
+        if args.eval:
+            from .data.metric import evaluate_detections
+            evaluate_detections(predictions, args.annotations, image_sizes, print_fn=print)
         if args.export:
-            out = Path(args.export).with_suffix('.json')
-            out.parent.mkdir(parents=True, exist_ok=True)
-            with open(out, 'wt') as fp:
-                json.dump(rows, fp)
-        print(f'inference done in {time.time() - start:.1f}s, {len(images)} images, {len(rows)} detections')
+            from .export import export, detection_rows
+            missing = [k for k in predictions.keys() if k not in image_sizes]
+            if missing:                                              # resumed samples: sizes come from the files
+                from PIL import Image
+                paths = dict(list_images(args.input))
+                for k in missing:
+                    with Image.open(paths[k]) as im:
+                        image_sizes[k] = im.size
+            export(predictions, args.export, image_sizes, args.export_format, args.threshold)
+            rows = detection_rows(predictions, image_sizes)
+        print(f'inference done in {time.time() - start:.1f}s, {len(image_ids)} images, {len(allc["image"])} detections')
+    return rows
+
+
+def _spawned(rank, world, port, argv):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    main(argv, _spawned_child=True)
+
+
+def inference(args, argv=None):
+    """detnet/inference.py:151-199 for an image folder."""
+    check_supported(args)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world == 1 and args.jobs > 1:                                  # -j N: one process per GPU (trainer/test.py:227-250)
+        import socket
+        import torch.multiprocessing as mp
+        n_gpu = torch.cuda.device_count()
+        if args.jobs > n_gpu:
+            raise RuntimeError(f'-j {args.jobs} but only {n_gpu} GPUs are visible (one process per GPU)')
+        with socket.socket() as sck:
+            sck.bind(('127.0.0.1', 0))
+            port = sck.getsockname()[1]
+        mp.spawn(_spawned, args=(args.jobs, port, list(argv or [])), nprocs=args.jobs, join=True)
+        return None
+    if not torch.cuda.is_available():
+        raise RuntimeError('the detector runs on the GPU only (HIP kernels, no CPU fallback)')
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
-    return rows if rank == 0 else None
+        dist.init_process_group('nccl', device_id=torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))))
+    try:
+        return run_rank(args, world, rank)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
 
 
-def main(argv=None):
+def main(argv=None, _spawned_child=False):
+    import sys
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
     if not args.output and not args.eval and not args.export:
         raise UserWarning("Please specify at least one path for output / evaluation / export")
-    inference(args)
+    return inference(args, argv)
 
 
 if __name__ == '__main__':

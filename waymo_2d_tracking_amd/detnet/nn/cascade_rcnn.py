@@ -4,12 +4,14 @@ This is the detector the reference builds through detectron2's
 ``Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml`` with the mask head off
 (/root/reference/detnet/nn/detectron2_det/__init__.py:21-60); the layer shapes follow the module tree printed in
 /root/reference/logs/12442/job.log:336-1221 and the op semantics SURVEY.md App. C (detectron2 is not vendored:
-"parity unpinned", weights are random-initialised unless a state dict is loaded).
+"parity unpinned" for the arithmetic; the STRUCTURE is pinned by tests/golden/x152_modules.json).  Weights: seeded random
+init, or a detectron2 / reference checkpoint through weights.load_state_dict_detectron2 (FrozenBN folded, fc1 permuted).
 
 MI355X-first layout: every activation is NHWC (torch.channels_last storage); FrozenBatchNorm is folded into the
 producing op; the hot per-frame ops run in hand-written HIP kernels (detnet/nn/ops.py):
-  * every 1x1 convolution (2/3 of the backbone FLOPs) and the box-head FC = one f32-MFMA GEMM with fused
-    bias / residual add / ReLU epilogue (wd_gemm_nt_f32),
+  * the box-head FC 12544 -> 1024 = the hand-written f32-MFMA GEMM (wd_gemm_nt_f32, split-K x2); the 1x1 convolutions
+    (2/3 of the backbone FLOPs) are GEMMs on the NHWC matrix view through hipBLASLt (Conv1x1.USE_LIBRARY_GEMM: the library
+    sustains 100-135 TFLOP/s on these shapes, ahead of the hand-written kernel), residual on the beta term,
   * the 47 deformable 3x3 convolutions = implicit GEMM with fused FrozenBN + ReLU (wd_deform_conv3x3_f32),
   * ROIPooler over the 4 FPN levels (wd_roi_pool_fpn_f32), RPN / box NMS (wd_nms_sorted_f32).
 Dense 3x3 / 7x7 convolutions and GroupNorm stay on PyTorch-ROCm (MIOpen) - the "Python host carries the graph".
@@ -299,7 +301,7 @@ class BoxHead(nn.Module):
         for c in self.convs:
             c.weight.data.copy_(_msra((256, 256, 3, 3), gen))
         # fc1 weight is stored for the NHWC flatten order (ph, pw, c); a checkpoint in detectron2's (c, ph, pw) order
-        # is permuted once by load_state_dict_detectron2()
+        # is permuted once by weights.load_state_dict_detectron2()
         self.fc1_weight = nn.Parameter(torch.empty(1024, 12544).normal_(0, math.sqrt(1.0 / 12544), generator=gen),
                                        requires_grad=False)
         self.fc1_bias = nn.Parameter(torch.zeros(1024), requires_grad=False)
