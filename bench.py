@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument('--collate', action='store_true',
                     help='e2e: gather every chunk\'s track rows to rank 0 inside the timed region (the submission collation over RCCL)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='e2e/detect: launch every frame eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--no-verify', action='store_true', help='skip the oracle replay of the timed output (after the timed region)')
     return ap.parse_args()
 

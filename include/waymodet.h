@@ -37,6 +37,11 @@ int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* heights, const
  * when IoU(i,j) > iou_threshold.  keep_mask (n) uint8 receives 1 for kept boxes; n_keep (device int32) their count.
  * workspace: wd_nms_workspace(n) bytes. */
 size_t wd_nms_workspace(int n);
+/* Static-shape survivor list: the first `cap` entries i (in mask order) with keep_mask[i] != 0 (and valid[i] != 0 when given) as
+ * out_idx[k] = order ? order[i] : i; unused slots are -1, *count = min(#survivors, cap) (device int32).  Replaces the
+ * `keep[:post_nms_topk]` / `[:topk]` slices behind detectron2's batched_nms without a host round trip. */
+int wd_select_kept(const uint8_t* keep_mask, const uint8_t* valid, const int64_t* order, int n, int cap, int64_t* out_idx,
+                   int32_t* count, void* stream);
 int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_threshold,
                       uint8_t* keep_mask, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
 

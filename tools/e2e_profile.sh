@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_e2e -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/e2e.json 2>/tmp/e2e.log
-python3 - "$(find /tmp/prof_e2e -name '*kernel_trace.csv' | head -1)" > $R/gpurun_out/e2e_steady.txt <<'PY'
+python3 - "$(find /tmp/prof_e2e -name '*kernel_trace.csv' | head -1)" $R/gpurun_out/e2e_frame_sequence.txt > $R/gpurun_out/e2e_steady.txt <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -25,5 +25,12 @@ for g in gaps[-8:]:
     print('   %8.1f us after %s before %s' % g)
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:60]:
     print('%7.3f ms/f %7.1f calls/f %8.1f us  %s' % (v[1] / nf, v[0] / nf, v[1] / v[0] * 1e3, k))
+# launch sequence of the last full frame (name, grid, us)
+with open(sys.argv[2], 'w') as fp:
+    one = rows[marks[-2]:marks[-1]]
+    t0 = int(one[0]['Start_Timestamp'])
+    for r in one:
+        fp.write('%9.1f %8.1f us  grid %-10s wg %-5s %s\n' % ((int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3,
+                 r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')), r['Kernel_Name'][:100]))
 PY
 cat $R/gpurun_out/e2e_steady.txt

@@ -42,7 +42,7 @@ def moving_frames(n_cameras, n_times, height, width, seed, device):
 class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
                  iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta='',
-                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None):
+                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True):
         self.dev = torch.device(device)
         # --tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image, folded into the pre-processing kernel
         self.tta_scale, self.tta_hflip = 1.0, False
@@ -66,8 +66,11 @@ class DetectTrackPipeline(object):
         R = self.max_chunks
         f64 = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=self.dev)
         # per-chunk detection slots (chunk-major; inside a chunk camera-major frames x 100 slots, category 0 = empty)
-        self.x, self.y, self.wd, self.ht, self.score = f64(R, n), f64(R, n), f64(R, n), f64(R, n), f64(R, n)
+        self.xywhs = f64(R, 5, n)                    # x, y, w, h, score rows of every chunk (one strided copy per frame)
+        self.x, self.y, self.wd, self.ht, self.score = (self.xywhs[:, q] for q in range(5))
         self.category = torch.zeros((R, n), dtype=torch.int32, device=self.dev)
+        self.n_dets_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.use_graph, self._graph = use_graph, None
         # per-chunk tracker output rows
         self.out_frame = torch.zeros((R, n + 1), dtype=torch.int64, device=self.dev)
         self.out_cat = torch.zeros((R, n + 1), dtype=torch.int32, device=self.dev)
@@ -88,37 +91,65 @@ class DetectTrackPipeline(object):
         self.chunk = 0                 # chunks of the current segment processed so far
         self.time = 0                  # frame time index into self.frames
         self.segments_done = 0
-        self.n_dets_last = 0
 
     @property
     def counts(self):
         """(rows, births) of the most recent chunk (device int64[2])."""
         return self.chunk_counts[max(self.chunk - 1, 0)]
 
-    def detect_frame(self, c, cam, j):
-        """Frame j of camera cam of chunk c -> wire-format detections in that frame's 100 slots."""
-        # decoded uint8 HWC RGB frame -> fused pre-processing kernel (ToTensor(scaling=False) + BGR + normalise + pad)
-        img = self.frames[(self.time + j) % self.n_times, cam].unsqueeze(0)
-        (boxes, scores, classes), = self.model.predict_device(img, self.tta_scale, self.tta_hflip)
+    def _detect_core(self, img):
+        """uint8 (1, H, W, 3) frame -> wire-format detections in 100 static slots: (xywhs (5, 100) float64, category (100) int32
+        with 0 = empty slot).  Static shapes, no host synchronisation: capturable as ONE hipGraph."""
+        boxes, scores, classes, cnt = self.model.predict_padded(img, self.tta_scale, self.tta_hflip)
         ho, wo = self.model.last_input_size
         if self.tta_hflip:                                                      # HFlipTTA.post_process: cx <- 1 - cx
             boxes = torch.stack((wo - boxes[:, 2], boxes[:, 1], wo - boxes[:, 0], boxes[:, 3]), dim=1)
         xywh, score, cat = detections_to_wire(boxes, scores, classes, wo, ho, self.w, self.h)
-        k = xywh.shape[0]
+        real = torch.arange(SLOTS, device=self.dev) < cnt.to(torch.int64)
+        cat = torch.where(real, cat, torch.zeros_like(cat))                     # unused slots: category 0 = ignored
+        return torch.cat((xywh.t(), score.unsqueeze(0)), 0).contiguous(), cat.contiguous(), cnt
+
+    def _capture(self):
+        """Warm up eagerly (MIOpen / TunableOp pick their kernels), then capture the whole per-frame detector as one hipGraph."""
+        from .detnet.nn import ops
+        saved, ops.EVENT_LOG = ops.EVENT_LOG, None          # no event records inside a capture
+        self._gin = torch.zeros((1, self.h, self.w, 3), dtype=torch.uint8, device=self.dev)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for t in range(3):
+                self._gin.copy_(self.frames[t % self.n_times, 0].unsqueeze(0))
+                self._detect_core(self._gin)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self._graph):
+            self._gout = self._detect_core(self._gin)
+        ops.EVENT_LOG = saved
+
+    def detect_frame(self, c, cam, j, eager=False):
+        """Frame j of camera cam of chunk c -> wire-format detections in that frame's 100 slots."""
+        # decoded uint8 HWC RGB frame -> fused pre-processing kernel (ToTensor(scaling=False) + BGR + normalise + pad)
+        img = self.frames[(self.time + j) % self.n_times, cam].unsqueeze(0)
+        if self.use_graph and not eager:
+            if self._graph is None:
+                self._capture()
+            self._gin.copy_(img)
+            self._graph.replay()
+            xywhs, cat, cnt = self._gout
+        else:
+            xywhs, cat, cnt = self._detect_core(img)
         a = (cam * self.fpc + j) * SLOTS
-        self.category[c, a:a + SLOTS] = 0                                       # unused slots: category 0 = ignored
-        self.x[c, a:a + k] = xywh[:, 0]; self.y[c, a:a + k] = xywh[:, 1]
-        self.wd[c, a:a + k] = xywh[:, 2]; self.ht[c, a:a + k] = xywh[:, 3]
-        self.score[c, a:a + k] = score
-        self.category[c, a:a + k] = cat
-        return k
+        self.xywhs[c, :, a:a + SLOTS] = xywhs
+        self.category[c, a:a + SLOTS] = cat
+        self.n_dets_dev += cnt
 
     def track(self, c):
         self.tracker.feed(self.x[c], self.y[c], self.wd[c], self.ht[c], self.score[c], self.category[c], self.frame_off,
                           self.stream_off, self.clip_w, self.clip_h, self.out_frame[c], self.out_cat[c], self.out_bbox[c],
                           self.out_score[c], self.out_id[c], self.chunk_counts[c])
 
-    def step(self, with_tracking=True):
+    def step(self, with_tracking=True, instrument=False):
         main = torch.cuda.current_stream()
         if self.chunk == self.max_chunks:                        # segment complete: fresh trackers, slots reused
             if with_tracking:
@@ -131,10 +162,9 @@ class DetectTrackPipeline(object):
             # slots of chunk c may still be read by a track() of the previous segment: it was queued before the most
             # recent one on the same in-order stream, so waiting for that one covers it
             main.wait_event(self._prev_done)
-        total = 0
         for cam in range(self.nc):
             for j in range(self.fpc):
-                total += self.detect_frame(c, cam, j)
+                self.detect_frame(c, cam, j, eager=(instrument and cam == 0 and j == 0))
         if with_tracking:
             filled = torch.cuda.Event()
             filled.record(main)
@@ -145,8 +175,7 @@ class DetectTrackPipeline(object):
                 self._prev_done.record(self.track_stream)
         self.chunk += 1
         self.time = (self.time + self.fpc) % self.n_times
-        self.n_dets_last = total
-        return total
+        return None
 
     def collate_last_chunk(self):
         """Optional timed leg (bench.py --collate): the rows of the chunk tracked LAST step travel to rank 0 the way the CLIs
@@ -239,7 +268,7 @@ def _pmc_traffic(tag):
 def run(args, world, rank, timed_steps):
     from .detnet.nn import ops
     fps = max(1, args.frames_per_step // 5)
-    pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '')
+    pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False))
     steps = args.steps or 3
     warmup = args.warmup if args.warmup is not None else 1
     track = args.stage == 'e2e'
@@ -250,7 +279,9 @@ def run(args, world, rank, timed_steps):
         if state['n'] == warmup:
             ops.EVENT_LOG = []
         state['n'] += 1
-        pipe.step(track)
+        # frame 0 of every timed step runs eagerly so that its deform-conv launches carry HIP events; the other frames replay
+        # the captured hipGraph of the same launches
+        pipe.step(track, instrument=ops.EVENT_LOG is not None)
         if track and getattr(args, 'collate', False):
             got = pipe.collate_last_chunk()
             if got is not None:
@@ -285,7 +316,7 @@ def run(args, world, rank, timed_steps):
                         % (', --tta ' + args.tta if getattr(args, 'tta', '') else '',
                            'SORT (max_age 2, min_hits 0, all boxes tracked; trackers resident for the whole segment)' if track else 'no tracking', 5, fps),
                roofline=roofline,
-               extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_last / frames, track_rows=n_out, births=births,
+               extra=dict(frames_per_step=frames, dets_per_frame=float(pipe.n_dets_dev.item()) / max(1, frames * state['n']), hip_graph=pipe._graph is not None, track_rows=n_out, births=births,
                           collated_rows_rank0=state.get('collated_rows')))
     res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters
     return res, steps, warmup

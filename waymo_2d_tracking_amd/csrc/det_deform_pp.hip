@@ -473,11 +473,11 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
     }
     const int groups = c / pp::CG;
     const int ntiles = batch * ((h + 7) / 8) * ((w + 7) / 8);
-    int n_cu = 256;
-    {
+    static int n_cu = 0;                                            // queried once (not inside a stream capture)
+    if (n_cu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     int nsplit = n_cu / groups;
     if (nsplit < 1) nsplit = 1;

@@ -182,9 +182,49 @@ __global__ __launch_bounds__(256) void nms_sweep_col_kernel(const unsigned long 
     if (tid == 0) *n_keep = total;
 }
 
+// First `cap` entries of a keep mask (in its order) as fixed-size index list: out_idx[k] = order ? order[i] : i of the k-th i
+// with keep[i] (and valid[i]); unused slots = -1; *count = min(total, cap).  One workgroup: ballot prefix sums, the running
+// base carried across 256-entry chunks.  Lets the proposal / detection lists keep a static shape (no host round trip for the
+// number of survivors).
+__global__ __launch_bounds__(256) void select_kept_kernel(const uint8_t* __restrict__ keep, const uint8_t* __restrict__ valid,
+                                                          const int64_t* __restrict__ order, int n, int cap,
+                                                          int64_t* __restrict__ out_idx, int32_t* __restrict__ count) {
+    __shared__ int wave_sum[4];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    for (int k = tid; k < cap; k += 256) out_idx[k] = -1;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + tid;
+        const bool f = i < n && keep[i] && (!valid || valid[i]);
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wave_sum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_sum[w];
+        const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (f && k < cap) out_idx[k] = order ? order[i] : (int64_t)i;
+        __syncthreads();
+        if (tid == 0) base_s += wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        __syncthreads();
+        if (base_s >= cap) break;
+    }
+    if (tid == 0) *count = base_s < cap ? base_s : cap;
+}
+
 }  // namespace
 
 extern "C" {
+
+int wd_select_kept(const uint8_t* keep_mask, const uint8_t* valid, const int64_t* order, int n, int cap, int64_t* out_idx,
+                   int32_t* count, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (n < 0 || cap <= 0 || !out_idx || !count || (n > 0 && !keep_mask)) { wt::set_error("wd_select_kept: bad argument"); return WT_ERR_INVALID; }
+    hipLaunchKernelGGL(select_kept_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, keep_mask, valid, order, n, cap, out_idx, count);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
 
 size_t wd_nms_workspace(int n) {
     const size_t nb = (size_t)(n + 63) / 64;

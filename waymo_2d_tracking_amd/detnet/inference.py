@@ -187,7 +187,7 @@ class ImageLoader(object):
                 if nxt is not None:
                     pending.append((nxt[0], pool.submit(self._decode, nxt[1])))
                 arr = fut.result()
-                t = torch.from_numpy(arr).pin_memory().cuda(non_blocking=True)
+                t = torch.from_numpy(np.array(arr, copy=True)).pin_memory().cuda(non_blocking=True)
                 yield image_id, t, (arr.shape[1], arr.shape[0])
 
 
@@ -260,19 +260,27 @@ def run_rank(args, world, rank):
             out_dir.mkdir(parents=True, exist_ok=True)
             print('saving', out_dir / 'detections.pkl')
             predictions.save(out_dir / 'detections.pkl')
-        image_sizes = {k: tuple(int(v) for v in sizes[i]) for i, k in enumerate(image_ids) if predictions.tested[i] and sizes[i, 0] > 0}
+        def image_sizes_in_order():
+            """{image_id: (width, height)} of every tested image in data-set order (the reference iterates coco.imgs); resumed
+            samples were not decoded in this run: their sizes come from the file headers."""
+            out, paths = {}, None
+            for i, k in enumerate(image_ids):
+                if not predictions.tested[predictions._index[k]]:
+                    continue
+                if sizes[i, 0] > 0:
+                    out[k] = (int(sizes[i, 0]), int(sizes[i, 1]))
+                else:
+                    from PIL import Image
+                    paths = paths or dict(list_images(args.input))
+                    with Image.open(paths[k]) as im:
+                        out[k] = im.size
+            return out
+        image_sizes = image_sizes_in_order() if (args.eval or args.export) else {}
         if args.eval:
             from .data.metric import evaluate_detections
             evaluate_detections(predictions, args.annotations, image_sizes, print_fn=print)
         if args.export:
             from .export import export, detection_rows
-            missing = [k for k in predictions.keys() if k not in image_sizes]
-            if missing:                                              # resumed samples: sizes come from the files
-                from PIL import Image
-                paths = dict(list_images(args.input))
-                for k in missing:
-                    with Image.open(paths[k]) as im:
-                        image_sizes[k] = im.size
             export(predictions, args.export, image_sizes, args.export_format, args.threshold)
             rows = detection_rows(predictions, image_sizes)
         print(f'inference done in {time.time() - start:.1f}s, {len(image_ids)} images, {len(allc["image"])} detections')

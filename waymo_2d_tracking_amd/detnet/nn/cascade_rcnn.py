@@ -268,7 +268,7 @@ class RPN(nn.Module):
         return self._anchors[key]
 
     def forward(self, feats, img_h, img_w):
-        """feats p2..p6 (batch 1) -> proposals (R,4), sorted by objectness."""
+        """feats p2..p6 (batch 1) -> (proposals (post_nms_topk, 4) sorted by objectness and zero-padded, count int32[1])."""
         boxes_l, scores_l, lvl_l = [], [], []
         for l, f in enumerate(feats):
             t = self.conv(f, relu=True)
@@ -285,10 +285,14 @@ class RPN(nn.Module):
             lvl_l.append(self._level_ids(l, k, f.device))
         boxes = torch.cat(boxes_l)
         scores = torch.cat(scores_l); lvls = torch.cat(lvl_l)
+        # find_top_rpn_proposals: drop empty boxes, per-level NMS, keep the `post` best.  Static shapes, no host round trip:
+        # an empty box keeps its slot but can neither suppress (group -1) nor be selected (valid mask); the result is always
+        # (post, 4) - unused rows are zero boxes - plus the device-side count of real proposals
         ok = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
-        boxes, scores, lvls = boxes[ok], scores[ok], lvls[ok]
-        keep = ops.batched_nms(boxes, scores, lvls, self.thr)[: self.post]
-        return boxes[keep]
+        lvls = torch.where(ok, lvls, torch.full_like(lvls, -1))
+        idx, count = ops.nms_select(boxes, scores, lvls, self.thr, self.post, valid=ok)
+        props = boxes[idx.clamp(min=0)] * (idx >= 0).unsqueeze(1).to(boxes.dtype)
+        return props, count
 
 
 class BoxHead(nn.Module):
@@ -369,16 +373,24 @@ class CascadeRCNN(nn.Module):
     def forward_normalized(self, x, img_h, img_w, proposals=None, intermediates=None):
         """Same, from the normalised / padded NHWC tensor that ops.preprocess (the fused HIP pre-processing kernel)
         or self.preprocess produce; (img_h, img_w) = the valid (unpadded) extent."""
+        b, s, c, cnt = self.forward_padded(x, img_h, img_w, proposals, intermediates)
+        k = int(cnt.item())                                   # the one host round trip of a frame (API boundary)
+        return b[:k], s[:k], c[:k]
+
+    def forward_padded(self, x, img_h, img_w, proposals=None, intermediates=None):
+        """The whole graph with static shapes and no host synchronisation (capturable as one hipGraph): returns
+        (boxes (topk, 4), scores (topk), classes (topk) int64, count int32[1]); rows >= count are padding."""
         feats = self.backbone(x)
         if proposals is None:
-            proposals = self.rpn(feats, img_h, img_w)
+            proposals, n_prop = self.rpn(feats, img_h, img_w)
+        else:
+            n_prop = torch.full((1,), proposals.shape[0], dtype=torch.int32, device=proposals.device)
         scales = [1.0 / s for s in (4, 8, 16, 32)]
         stage_scores = []
         stage_out = []
         boxes = proposals
-        # the number of proposals is data dependent; the box heads run on a row count rounded up to a multiple of 32 (zero
-        # boxes, sliced off again) so that the library convolutions / GEMMs see a small fixed set of shapes - with
-        # cudnn.benchmark every NEW shape costs a solver search
+        # the box heads run on a row count rounded up to a multiple of 32 (zero boxes) so that the library convolutions /
+        # GEMMs see a small fixed set of shapes - with cudnn.benchmark every NEW shape costs a solver search
         n_roi = boxes.shape[0]
         n_pad = (-n_roi) % 32 if n_roi else 0
         for k in range(3):
@@ -394,18 +406,30 @@ class CascadeRCNN(nn.Module):
             boxes = ops.decode_boxes(deltas, boxes, self.CASCADE_WEIGHTS[k], None, (img_h, img_w) if k < 2 else None)
         scores = (stage_scores[0] + stage_scores[1] + stage_scores[2]) * (1.0 / 3)
         if intermediates is not None:
-            intermediates.update(feats=feats, proposals=proposals, stage_out=stage_out, boxes=boxes, scores=scores)
-        return self.inference(boxes, scores, img_h, img_w)
+            intermediates.update(feats=feats, proposals=proposals, stage_out=stage_out, boxes=boxes, scores=scores, n_proposals=n_prop)
+        return self.inference(boxes, scores, img_h, img_w, n_prop)
 
-    def inference(self, boxes, scores, img_h, img_w):
-        """detectron2 fast_rcnn_inference_single_image (class-agnostic boxes)."""
-        valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
-        boxes, scores = boxes[valid], scores[valid]
-        scores = scores[:, :-1]
+    def inference(self, boxes, scores, img_h, img_w, n_valid=None):
+        """detectron2 fast_rcnn_inference_single_image (class-agnostic boxes) with static shapes: every (box, class) pair is a
+        candidate slot; a slot is real when its box row is a real proposal, box and scores are finite and the class score
+        exceeds the threshold.  Real candidates keep their row-major (box, class) order under the stable score sort, exactly
+        like `scores[mask]` / `mask.nonzero()` of the reference; padding slots sort behind them (score -1), never suppress (group
+        -1) and are never selected.  Returns (boxes (topk,4), scores (topk), classes (topk), count int32[1])."""
+        r, nc = scores.shape[0], scores.shape[1] - 1
+        row_ok = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+        if n_valid is not None:
+            row_ok = row_ok & (torch.arange(r, device=boxes.device) < n_valid.to(torch.int64))
         boxes = clip_boxes(boxes, img_h, img_w)
-        mask = scores > self.score_thresh
-        inds = mask.nonzero()
-        b = boxes[inds[:, 0]]
-        s = scores[mask]
-        keep = ops.batched_nms(b, s, inds[:, 1].to(torch.int32), self.nms_thresh)[: self.topk]
-        return b[keep], s[keep], inds[keep, 1]
+        s = scores[:, :-1]
+        real = (s > self.score_thresh) & row_ok.unsqueeze(1)                       # (r, nc)
+        flat_s = torch.where(real, s, torch.full_like(s, -1.0)).reshape(-1)
+        cls = torch.arange(nc, device=boxes.device, dtype=torch.int32).repeat(r)
+        flat_c = torch.where(real.reshape(-1), cls, torch.full_like(cls, -1))
+        flat_b = boxes.repeat_interleave(nc, dim=0)
+        idx, count = ops.nms_select(flat_b, flat_s, flat_c, self.nms_thresh, self.topk, valid=real.reshape(-1))
+        sel = idx.clamp(min=0)
+        got = (idx >= 0)
+        out_b = flat_b[sel] * got.unsqueeze(1).to(flat_b.dtype)
+        out_s = flat_s[sel] * got.to(flat_s.dtype)
+        out_c = (sel % nc) * got.to(torch.int64)
+        return out_b, out_s, out_c, count

@@ -104,6 +104,14 @@ class Detectron2Det(Module):
         self.last_input_size = (ho, wo)
         return [self.model.forward_normalized(xn[i:i + 1], ho, wo) for i in range(xn.shape[0])]
 
+    @torch.no_grad()
+    def predict_padded(self, x, scale=1.0, hflip=False, vflip=False):
+        """One image, static shapes, no host synchronisation (hipGraph-capturable): (boxes (100,4), scores (100), classes (100),
+        count int32[1]) in pixels of the transformed image; rows >= count are padding."""
+        xn, (ho, wo) = ops.preprocess(x, scale, hflip, vflip, True, PIXEL_MEAN, PIXEL_STD, 32)
+        self.last_input_size = (ho, wo)
+        return self.model.forward_padded(xn, ho, wo)
+
     def _predict_multiscale(self, x, scale, hflip, vflip, max_size=4000):
         """enable_tta(): GeneralizedRCNNWithTTA restated (detectron2 0.1.3 modeling/test_time_augmentation.py, FLIP False): one
         detector pass per min size (ResizeShortestEdge), boxes rescaled to the base image, all detections merged by the model's
@@ -174,6 +182,9 @@ class Detectron2Det(Module):
         return output[0] if single else output
 
 
+_WIRE_SCALE = {}
+
+
 def detections_to_wire(boxes, scores, classes, width, height, out_width=None, out_height=None):
     """Device-side twin of Detectron2Det.predict (:119-131) + COCODetection.load_prediction
     (/root/reference/detnet/data/coco.py:229-252): the [x, y, w, h] integers, 5-decimal score and category id that
@@ -187,7 +198,10 @@ def detections_to_wire(boxes, scores, classes, width, height, out_width=None, ou
     wh = bx[:, 2:4] - bx[:, 0:2]
     # TTA: the boxes are normalised in the transformed (resized) image and scaled by the ORIGINAL size (tta.py: boxes are
     # normalised, so ResizeTTA needs no undo; coco.py:249 multiplies by the image's own width / height)
-    scale = torch.tensor([out_width or width, out_height or height], dtype=torch.float64, device=boxes.device)
+    key = (out_width or width, out_height or height, boxes.device)
+    scale = _WIRE_SCALE.get(key)
+    if scale is None:                                      # cached: no host-to-device copy on the steady-state path (hipGraph capture)
+        scale = _WIRE_SCALE[key] = torch.tensor(key[:2], dtype=torch.float64, device=boxes.device)
     c64 = center.double() * scale
     wh64 = wh.double() * scale
     lt = c64 - wh64 / 2

@@ -56,10 +56,15 @@ _nms_ws = {}
 
 def nms_sorted(boxes, idxs, iou_threshold):
     """boxes (n,4) xyxy already sorted by descending score; idxs (n) int32 group ids or None -> bool keep mask."""
+    return nms_sorted_mask(boxes, idxs, iou_threshold).bool()
+
+
+def nms_sorted_mask(boxes, idxs, iou_threshold):
+    """nms_sorted as a uint8 mask (no dtype conversion launch)."""
     n = boxes.shape[0]
     keep = torch.zeros(n, dtype=torch.uint8, device=boxes.device)
     if n == 0:
-        return keep.bool()
+        return keep
     boxes = boxes.contiguous().float()
     if idxs is not None:
         idxs = idxs.contiguous().to(torch.int32)
@@ -73,7 +78,24 @@ def nms_sorted(boxes, idxs, iou_threshold):
     cnt = torch.zeros(1, dtype=torch.int32, device=boxes.device)
     _lib.check(lib.wd_nms_sorted_f32(_p(boxes), _p(idxs), C.c_int(n), C.c_float(iou_threshold), _p(keep), _p(cnt),
                                      _p(ws), C.c_size_t(ws.numel()), _stream()), 'wd_nms_sorted_f32')
-    return keep.bool()
+    return keep
+
+
+def nms_select(boxes, scores, idxs, iou_threshold, cap, valid=None):
+    """Static-shape batched_nms(...)[:cap]: (idx (cap,) int64 padded with -1, count int32[1] on the device).  `valid` (bool, n)
+    marks real candidates; padding entries must carry a score below every real one and should get a group id of their own
+    (they are kept by the NMS but never selected).  No host synchronisation."""
+    n = boxes.shape[0]
+    order = torch.argsort(scores, descending=True, stable=True)
+    sb = boxes[order]
+    si = None if idxs is None else idxs[order]
+    keep = nms_sorted_mask(sb, si, iou_threshold)
+    out = torch.empty(cap, dtype=torch.int64, device=boxes.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=boxes.device)
+    v = None if valid is None else valid[order].to(torch.uint8).contiguous()
+    _lib.check(_lib.lib().wd_select_kept(_p(keep), _p(v), _p(order), C.c_int(n), C.c_int(cap), _p(out), _p(cnt), _stream()),
+               'wd_select_kept')
+    return out, cnt
 
 
 def batched_nms(boxes, scores, idxs, iou_threshold):

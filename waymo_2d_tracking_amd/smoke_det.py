@@ -6,10 +6,10 @@ import torch
 def run(track_streams=None):
     from .bench_e2e import DetectTrackPipeline, check_against
     pipe = DetectTrackPipeline(n_cameras=2, frames_per_camera=2, height=256, width=384, seed=0, distinct_times=6)
-    n = 0
     for _ in range(3):
-        n += pipe.step(True)
+        pipe.step(True)
     torch.cuda.synchronize()
+    n = int(pipe.n_dets_dev.item())
     n_out, births = [int(v) for v in pipe.counts.cpu().tolist()]
     assert n_out >= 0, 'SORT kernel status %d' % -n_out
     if track_streams is not None:
