@@ -45,6 +45,38 @@ int wd_select_kept(const uint8_t* keep_mask, const uint8_t* valid, const int64_t
 int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_threshold,
                       uint8_t* keep_mask, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* --- fused, static-shape tail of the detector (csrc/det_tail.hip): one launch per step, no host round trip ------------
+ * RPN.predict_proposals (detectron2 proposal_utils.find_top_rpn_proposals, called from detectron2_det/__init__.py:74 via the
+ * model forward): per FPN level the k best objectness logits (torch.topk(sorted=True); ties: lower anchor index first) and
+ * apply_deltas + clip of exactly those anchors.  Level l's rows start at sum_{m<l} min(k, n_m).  group = level, or -1 for an
+ * empty box (dropped by find_top_rpn_proposals); valid = 0 for an empty box.  Device pointers in host arrays. */
+size_t wd_rpn_topk_workspace(const int* n_per_level, int n_levels, int k);
+int wd_rpn_topk_decode_f32(const float* const* logits, const float* const* deltas, const float* const* anchors,
+                           const int* n_per_level, int n_levels, int k, float img_h, float img_w, float scale_clamp,
+                           float* out_boxes, float* out_scores, int32_t* out_group, uint8_t* out_valid, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* Stable descending score sort of n <= 8192 candidate rows, gathered into sorted order (the `scores.sort(descending=True)` in
+ * front of batched_nms); out_order[t] = source row of sorted row t. */
+int wd_sort_candidates_f32(const float* boxes, const float* scores, const int32_t* group, const uint8_t* valid, int n,
+                           float* out_boxes, float* out_scores, int32_t* out_group, uint8_t* out_valid, int64_t* out_order,
+                           void* stream);
+/* fast_rcnn_inference_single_image candidates: every (row, class) pair of the last cascade stage, score = (s0 + s1 + s2) / 3 of
+ * the three stages' softmax (rows x (classes + 1)); a pair is real when its row < *n_valid, box and scores are finite and the
+ * class score > score_thresh; real pairs sort first (stable), boxes are clipped to the image.  group = class or -1. */
+int wd_box_candidates_f32(const float* boxes, const float* s0, const float* s1, const float* s2, const int32_t* n_valid, int rows,
+                          int num_classes, float score_thresh, float img_h, float img_w, float* out_boxes, float* out_scores,
+                          int32_t* out_group, uint8_t* out_valid, int64_t* out_order, void* stream);
+/* First `cap` kept & valid sorted candidates -> fixed-size outputs (unused rows zero) + device count: the proposal list
+ * (out_scores / out_class NULL) or the final detections (class = order % num_classes). */
+int wd_gather_kept_f32(const uint8_t* keep, const uint8_t* valid, const float* boxes, const float* scores, const int64_t* order,
+                       int n, int cap, int num_classes, float* out_boxes, float* out_scores, int64_t* out_class, int32_t* count,
+                       void* stream);
+/* Detectron2Det.predict (detectron2_det/__init__.py:119-131) + COCODetection.load_prediction (detnet/data/coco.py:229-252) on the
+ * device: pixel boxes of the (possibly h-flipped) in_w x in_h network input -> integer [x, y, w, h] of the out_w x out_h image,
+ * 5-decimal score (xywhs: 5 rows of n doubles) and category id = class + 1 (0 for slots >= *count). */
+int wd_detections_to_wire(const float* boxes, const float* scores, const int64_t* classes, const int32_t* count, int n, int in_w,
+                          int in_h, int hflip, int out_w, int out_h, double* xywhs, int32_t* category, void* stream);
+
 /* detectron2 DeformConv / ModulatedDeformConv forward (job.log:412-415), kernel 3x3, dilation 1,
  * deformable_groups 1:
  *   x      : (N, H, W, C_in) NHWC float32

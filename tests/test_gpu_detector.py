@@ -224,7 +224,7 @@ def test_inference_cli_on_image_folder(tmp_path):
     assert list(dict.fromkeys(r['image_id'] for r in rows2)) == list(dict.fromkeys(r['image_id'] for r in rows))
     # --auto-contrast = ImageOps.autocontrast, bit for bit
     img = Image.open(I.list_images(str(root))[0][1]).convert('RGB')
-    got = I.autocontrast_(torch.from_numpy(np.asarray(img)).cuda()).cpu().numpy()
+    got = I.autocontrast_(torch.from_numpy(np.array(img)).cuda()).cpu().numpy()
     assert np.array_equal(got, np.asarray(ImageOps.autocontrast(img)))
     flat = Image.fromarray(np.full((8, 8, 3), 77, np.uint8))
     assert np.array_equal(I.autocontrast_(torch.from_numpy(np.asarray(flat)).cuda()).cpu().numpy(), np.asarray(ImageOps.autocontrast(flat)))

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .detnet.nn import ops
 from .detnet.nn.detectron2_det import Detectron2Det, detections_to_wire
 from .devpath import StreamingTracker
 from .tuning import enable_gemm_tuning
@@ -102,12 +103,9 @@ class DetectTrackPipeline(object):
         with 0 = empty slot).  Static shapes, no host synchronisation: capturable as ONE hipGraph."""
         boxes, scores, classes, cnt = self.model.predict_padded(img, self.tta_scale, self.tta_hflip)
         ho, wo = self.model.last_input_size
-        if self.tta_hflip:                                                      # HFlipTTA.post_process: cx <- 1 - cx
-            boxes = torch.stack((wo - boxes[:, 2], boxes[:, 1], wo - boxes[:, 0], boxes[:, 3]), dim=1)
-        xywh, score, cat = detections_to_wire(boxes, scores, classes, wo, ho, self.w, self.h)
-        real = torch.arange(SLOTS, device=self.dev) < cnt.to(torch.int64)
-        cat = torch.where(real, cat, torch.zeros_like(cat))                     # unused slots: category 0 = ignored
-        return torch.cat((xywh.t(), score.unsqueeze(0)), 0).contiguous(), cat.contiguous(), cnt
+        # HFlipTTA.post_process + Detectron2Det.predict + load_prediction in one launch; unused slots: category 0 = ignored
+        xywhs, cat = ops.detections_to_wire(boxes, scores, classes, cnt, wo, ho, self.w, self.h, self.tta_hflip)
+        return xywhs, cat, cnt
 
     def _capture(self):
         """Warm up eagerly (MIOpen / TunableOp pick their kernels), then capture the whole per-frame detector as one hipGraph."""

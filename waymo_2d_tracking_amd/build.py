@@ -34,6 +34,7 @@ UNITS = {
     'det_gemm.hip': ['-munsafe-fp-atomics'],
     'det_misc.hip': [],
     'det_preprocess.hip': ['-ffp-contract=off'],
+    'det_tail.hip': ['-ffp-contract=off'],
     'det_backward.hip': ['-munsafe-fp-atomics'],
 }
 

@@ -10,6 +10,7 @@
 // bilinear coordinates are computed once per pixel and the planar / interleaved source reads stay coalesced.  Bilinear arithmetic follows ATen's
 // upsample_bilinear2d (area_pixel_compute_source_index, float accumulation type).
 #include "common.h"
+#include "det_boxmath.h"
 #include "../../include/waymodet.h"
 
 namespace {
@@ -98,22 +99,7 @@ __global__ __launch_bounds__(256) void decode_boxes_kernel(const float4* __restr
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const long long j = index ? index[i] : i;
-    const float4 d = deltas[j], b = boxes[j];
-    const float widths = b.z - b.x, heights = b.w - b.y;
-    const float ctr_x = b.x + 0.5f * widths, ctr_y = b.y + 0.5f * heights;
-    // tensor / python_scalar in torch is a multiplication by the float reciprocal of the scalar (BinaryDivTrueKernel)
-    const float dx = d.x * (1.0f / wx), dy = d.y * (1.0f / wy);
-    float dw = d.z * (1.0f / ww), dh = d.w * (1.0f / wh);
-    dw = dw > scale_clamp ? scale_clamp : dw;             // torch.clamp(max=): NaN propagates
-    dh = dh > scale_clamp ? scale_clamp : dh;
-    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
-    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
-    float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
-    if (clip_w > 0.f) {                                    // Boxes.clip: clamp(min=0, max=w|h), NaN stays NaN
-        o.x = o.x < 0.f ? 0.f : (o.x > clip_w ? clip_w : o.x); o.z = o.z < 0.f ? 0.f : (o.z > clip_w ? clip_w : o.z);
-        o.y = o.y < 0.f ? 0.f : (o.y > clip_h ? clip_h : o.y); o.w = o.w < 0.f ? 0.f : (o.w > clip_h ? clip_h : o.w);
-    }
-    out[i] = o;
+    out[i] = wd::decode_box(deltas[j], boxes[j], wx, wy, ww, wh, scale_clamp, clip_w, clip_h);
 }
 
 }  // namespace

@@ -269,29 +269,22 @@ class RPN(nn.Module):
 
     def forward(self, feats, img_h, img_w):
         """feats p2..p6 (batch 1) -> (proposals (post_nms_topk, 4) sorted by objectness and zero-padded, count int32[1])."""
-        boxes_l, scores_l, lvl_l = [], [], []
+        logits_l, deltas_l, anchors_l = [], [], []
         for l, f in enumerate(feats):
             t = self.conv(f, relu=True)
             logits = self.objectness(t)                    # (1,3,H,W) channels_last == (H,W,A) order in memory
             deltas = self.deltas(t)                        # (1,12,H,W)
-            h, w = f.shape[2], f.shape[3]
-            logits = logits.permute(0, 2, 3, 1).reshape(-1)
-            deltas = deltas.permute(0, 2, 3, 1).reshape(-1, 4)
-            k = min(self.pre, logits.numel())
-            top, idx = torch.topk(logits, k, sorted=True)
-            # apply_deltas(deltas[idx], anchors[idx]) + clip_boxes in one launch (wd_decode_boxes_f32, same arithmetic)
-            prop = ops.decode_boxes(deltas, self.anchors(l, h, w, f.device), (1.0, 1.0, 1.0, 1.0), idx, (img_h, img_w))
-            boxes_l.append(prop); scores_l.append(top)
-            lvl_l.append(self._level_ids(l, k, f.device))
-        boxes = torch.cat(boxes_l)
-        scores = torch.cat(scores_l); lvls = torch.cat(lvl_l)
-        # find_top_rpn_proposals: drop empty boxes, per-level NMS, keep the `post` best.  Static shapes, no host round trip:
-        # an empty box keeps its slot but can neither suppress (group -1) nor be selected (valid mask); the result is always
-        # (post, 4) - unused rows are zero boxes - plus the device-side count of real proposals
-        ok = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
-        lvls = torch.where(ok, lvls, torch.full_like(lvls, -1))
-        idx, count = ops.nms_select(boxes, scores, lvls, self.thr, self.post, valid=ok)
-        props = boxes[idx.clamp(min=0)] * (idx >= 0).unsqueeze(1).to(boxes.dtype)
+            logits_l.append(logits.permute(0, 2, 3, 1).reshape(-1))
+            deltas_l.append(deltas.permute(0, 2, 3, 1).reshape(-1, 4))
+            anchors_l.append(self.anchors(l, f.shape[2], f.shape[3], f.device))
+        # per level: torch.topk(logits, pre) + apply_deltas(deltas[idx], anchors[idx]) + clip_boxes for all levels in 2-3 launches
+        # (wd_rpn_topk_decode_f32).  find_top_rpn_proposals: drop empty boxes, per-level NMS, keep the `post` best - static
+        # shapes, no host round trip: an empty box keeps its slot but can neither suppress (group -1) nor be selected (valid
+        # 0); the result is always (post, 4) - unused rows are zero boxes - plus the device-side count of real proposals
+        boxes, scores, lvls, ok = ops.rpn_topk_decode(logits_l, deltas_l, anchors_l, self.pre, img_h, img_w)
+        sb, ss, sg, sv, order = ops.sort_candidates(boxes, scores, lvls, ok)
+        keep = ops.nms_sorted_mask(sb, sg, self.thr)
+        props, count = ops.gather_kept(keep, sv, sb, ss, order, self.post)
         return props, count
 
 
@@ -404,17 +397,29 @@ class CascadeRCNN(nn.Module):
             # stages 0 / 1: the next stage starts with clip_boxes -> fused into the decode launch; the last stage's
             # boxes stay unclipped for the isfinite filter of inference()
             boxes = ops.decode_boxes(deltas, boxes, self.CASCADE_WEIGHTS[k], None, (img_h, img_w) if k < 2 else None)
-        scores = (stage_scores[0] + stage_scores[1] + stage_scores[2]) * (1.0 / 3)
         if intermediates is not None:
+            scores = (stage_scores[0] + stage_scores[1] + stage_scores[2]) * (1.0 / 3)
             intermediates.update(feats=feats, proposals=proposals, stage_out=stage_out, boxes=boxes, scores=scores, n_proposals=n_prop)
-        return self.inference(boxes, scores, img_h, img_w, n_prop)
+        return self.inference(boxes, stage_scores, img_h, img_w, n_prop)
 
-    def inference(self, boxes, scores, img_h, img_w, n_valid=None):
-        """detectron2 fast_rcnn_inference_single_image (class-agnostic boxes) with static shapes: every (box, class) pair is a
-        candidate slot; a slot is real when its box row is a real proposal, box and scores are finite and the class score
-        exceeds the threshold.  Real candidates keep their row-major (box, class) order under the stable score sort, exactly
-        like `scores[mask]` / `mask.nonzero()` of the reference; padding slots sort behind them (score -1), never suppress (group
-        -1) and are never selected.  Returns (boxes (topk,4), scores (topk), classes (topk), count int32[1])."""
+    def inference(self, boxes, stage_scores, img_h, img_w, n_valid=None):
+        """detectron2 fast_rcnn_inference_single_image (class-agnostic boxes) with static shapes, in 4 launches: every (box,
+        class) pair is a candidate slot; a slot is real when its box row is a real proposal, box and scores are finite and the
+        class score (mean of the three stages' softmax) exceeds the threshold.  Real candidates keep their row-major (box,
+        class) order under the stable score sort, exactly like `scores[mask]` / `mask.nonzero()` of the reference; padding
+        slots sort behind them (score -1), never suppress (group -1) and are never selected.
+        Returns (boxes (topk,4), scores (topk), classes (topk), count int32[1])."""
+        s0, s1, s2 = stage_scores
+        nc = s0.shape[1] - 1
+        if s0.shape[0] * nc > 8192:                       # one-workgroup sort limit (1000 proposals x 4 Waymo classes = 4000)
+            return self._inference_many_classes(boxes, (s0 + s1 + s2) * (1.0 / 3), img_h, img_w, n_valid)
+        sb, ss, sg, sv, order = ops.box_candidates(boxes, s0, s1, s2, n_valid, self.score_thresh, img_h, img_w)
+        keep = ops.nms_sorted_mask(sb, sg, self.nms_thresh)
+        return ops.gather_kept(keep, sv, sb, ss, order, self.topk, nc)
+
+    def _inference_many_classes(self, boxes, scores, img_h, img_w, n_valid=None):
+        """Same contract for candidate counts beyond the fused kernel's limit (e.g. the 80-class COCO checkpoint): the
+        candidates are built with torch ops, sort + NMS + selection through ops.nms_select."""
         r, nc = scores.shape[0], scores.shape[1] - 1
         row_ok = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
         if n_valid is not None:

@@ -182,15 +182,15 @@ class Detectron2Det(Module):
         return output[0] if single else output
 
 
-_WIRE_SCALE = {}
-
-
 def detections_to_wire(boxes, scores, classes, width, height, out_width=None, out_height=None):
     """Device-side twin of Detectron2Det.predict (:119-131) + COCODetection.load_prediction
     (/root/reference/detnet/data/coco.py:229-252): the [x, y, w, h] integers, 5-decimal score and category id that
     the detection JSON carries between inference.py and tracking/track.py.  float32 box arithmetic, float64 scaling
     and truncation toward zero, exactly in that order.  (round(score, 5) is rint(score*1e5)/1e5 here; Python's
     correctly-rounded round() differs only on exact decimal half-ways.)"""
+    if boxes.is_cuda:                                      # one launch (csrc/det_tail.hip wire_kernel), same arithmetic
+        xywhs, cat = ops.detections_to_wire(boxes, scores, classes, None, width, height, out_width or width, out_height or height)
+        return xywhs[:4].t(), xywhs[4], cat
     bx = boxes.clone()
     bx[:, 0::2] *= 1.0 / width
     bx[:, 1::2] *= 1.0 / height
@@ -198,10 +198,7 @@ def detections_to_wire(boxes, scores, classes, width, height, out_width=None, ou
     wh = bx[:, 2:4] - bx[:, 0:2]
     # TTA: the boxes are normalised in the transformed (resized) image and scaled by the ORIGINAL size (tta.py: boxes are
     # normalised, so ResizeTTA needs no undo; coco.py:249 multiplies by the image's own width / height)
-    key = (out_width or width, out_height or height, boxes.device)
-    scale = _WIRE_SCALE.get(key)
-    if scale is None:                                      # cached: no host-to-device copy on the steady-state path (hipGraph capture)
-        scale = _WIRE_SCALE[key] = torch.tensor(key[:2], dtype=torch.float64, device=boxes.device)
+    scale = torch.tensor([out_width or width, out_height or height], dtype=torch.float64, device=boxes.device)
     c64 = center.double() * scale
     wh64 = wh.double() * scale
     lt = c64 - wh64 / 2

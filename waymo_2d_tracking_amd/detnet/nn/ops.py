@@ -218,6 +218,93 @@ def conv3x3_few(x, w2, bias, n_out, stride=1):
     return out
 
 
+SCALE_CLAMP = 4.135166556742356          # log(1000 / 16), Box2BoxTransform
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def rpn_topk_decode(logits, deltas, anchors, k, img_h, img_w):
+    """Per FPN level: the k best objectness logits (sorted) and apply_deltas + clip of those anchors, all levels in 2-3
+    launches (wd_rpn_topk_decode_f32).  logits[l] (n_l,), deltas[l] / anchors[l] (n_l, 4) float32.
+    Returns (boxes (R,4), scores (R), group (R) int32 = level or -1 for an empty box, valid (R) uint8), R = sum min(k, n_l)."""
+    logits = [t.contiguous().float() for t in logits]
+    deltas = [t.contiguous().float() for t in deltas]
+    anchors = [t.contiguous().float() for t in anchors]
+    n = [int(t.numel()) for t in logits]
+    dev = logits[0].device
+    rows = sum(min(k, v) for v in n)
+    counts = (C.c_int * len(n))(*n)
+    lib = _lib.lib()
+    need = int(lib.wd_rpn_topk_workspace(counts, C.c_int(len(n)), C.c_int(k)))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    boxes = torch.empty((rows, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty(rows, dtype=torch.float32, device=dev)
+    group = torch.empty(rows, dtype=torch.int32, device=dev)
+    valid = torch.empty(rows, dtype=torch.uint8, device=dev)
+    _lib.check(lib.wd_rpn_topk_decode_f32(_ptr_array(logits), _ptr_array(deltas), _ptr_array(anchors), counts, C.c_int(len(n)),
+                                          C.c_int(k), C.c_float(img_h), C.c_float(img_w), C.c_float(SCALE_CLAMP), _p(boxes),
+                                          _p(scores), _p(group), _p(valid), _p(ws), C.c_size_t(need), _stream()),
+               'wd_rpn_topk_decode_f32')
+    return boxes, scores, group, valid
+
+
+def _sorted_outputs(n, dev):
+    return (torch.empty((n, 4), dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev),
+            torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.uint8, device=dev),
+            torch.empty(n, dtype=torch.int64, device=dev))
+
+
+def sort_candidates(boxes, scores, group, valid):
+    """Stable descending score sort of <= 8192 candidate rows + gather: (boxes, scores, group, valid, order) sorted."""
+    n = boxes.shape[0]
+    out = _sorted_outputs(n, boxes.device)
+    _lib.check(_lib.lib().wd_sort_candidates_f32(_p(boxes), _p(scores), _p(group), _p(valid), C.c_int(n), *[_p(t) for t in out],
+                                                 _stream()), 'wd_sort_candidates_f32')
+    return out
+
+
+def box_candidates(boxes, s0, s1, s2, n_valid, score_thresh, img_h, img_w):
+    """fast_rcnn_inference_single_image candidates (every (row, class) pair; score = mean softmax of the three stages), sorted
+    by descending score with the real ones first: (clipped boxes, scores, group = class | -1, valid, order)."""
+    r, nc = s0.shape[0], s0.shape[1] - 1
+    out = _sorted_outputs(r * nc, boxes.device)
+    _lib.check(_lib.lib().wd_box_candidates_f32(_p(boxes.contiguous()), _p(s0.contiguous()), _p(s1.contiguous()), _p(s2.contiguous()),
+                                                _p(n_valid), C.c_int(r), C.c_int(nc), C.c_float(score_thresh), C.c_float(img_h),
+                                                C.c_float(img_w), *[_p(t) for t in out], _stream()), 'wd_box_candidates_f32')
+    return out
+
+
+def gather_kept(keep, valid, boxes, scores, order, cap, num_classes=0):
+    """The first `cap` kept & valid sorted candidates as fixed-size outputs (unused rows zero) and the device-side count.
+    num_classes == 0: proposals -> (boxes (cap,4), count); else detections -> (boxes, scores, classes int64, count)."""
+    dev = boxes.device
+    ob = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    if num_classes:
+        osc = torch.empty(cap, dtype=torch.float32, device=dev)
+        oc = torch.empty(cap, dtype=torch.int64, device=dev)
+    else:
+        osc = oc = None
+    _lib.check(_lib.lib().wd_gather_kept_f32(_p(keep), _p(valid), _p(boxes), _p(scores), _p(order), C.c_int(boxes.shape[0]),
+                                             C.c_int(cap), C.c_int(num_classes), _p(ob), _p(osc), _p(oc), _p(cnt), _stream()),
+               'wd_gather_kept_f32')
+    return (ob, osc, oc, cnt) if num_classes else (ob, cnt)
+
+
+def detections_to_wire(boxes, scores, classes, count, in_w, in_h, out_w, out_h, hflip=False):
+    """Pixel boxes of the network input -> wire values of the detection JSON in one launch: (xywhs (5, n) float64 = integer
+    x, y, w, h and the 5-decimal score, category (n) int32 = class + 1, 0 for slots >= count)."""
+    n = boxes.shape[0]
+    xywhs = torch.empty((5, n), dtype=torch.float64, device=boxes.device)
+    cat = torch.empty(n, dtype=torch.int32, device=boxes.device)
+    _lib.check(_lib.lib().wd_detections_to_wire(_p(boxes.contiguous()), _p(scores.contiguous()), _p(classes.contiguous()), _p(count),
+                                                C.c_int(n), C.c_int(in_w), C.c_int(in_h), C.c_int(1 if hflip else 0), C.c_int(out_w),
+                                                C.c_int(out_h), _p(xywhs), _p(cat), _stream()), 'wd_detections_to_wire')
+    return xywhs, cat
+
+
 def decode_boxes(deltas, boxes, weights, index=None, clip=None, scale_clamp=4.135166556742356):
     """apply_deltas(deltas[index], boxes[index], weights) [+ clip to (h, w)] in one launch; (n,4) float32 xyxy."""
     deltas = deltas.contiguous().float()
