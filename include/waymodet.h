@@ -45,6 +45,14 @@ int wd_select_kept(const uint8_t* keep_mask, const uint8_t* valid, const int64_t
 int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_threshold,
                       uint8_t* keep_mask, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* 1x1 convolution with residual (detectron2 BottleneckBlock conv3 + shortcut + ReLU, job.log:412-415) as ONE hipBLASLt GEMM:
+ * out (m, n) = relu?(a (m, k) . w (n, k)^T + residual (m, n) + bias (n)), row-major; residual may alias out.  beta = 1 carries
+ * the residual, the RELU_BIAS epilogue the folded FrozenBN shift.  The first call per shape (outside a stream capture) times the
+ * heuristic's candidates and caches the fastest; hipBLASLt itself is resolved with dlopen at first use. */
+int wd_gemm_lt_f32(const float* a, const float* w, const float* bias, const float* residual, float* out, int m, int n, int k,
+                   int relu, void* workspace, size_t workspace_bytes, void* stream);
+int wd_gemm_lt_plan_info(int m, int n, int k, int relu, int has_bias, int has_residual, float* best_us, int* candidates);
+
 /* --- fused, static-shape tail of the detector (csrc/det_tail.hip): one launch per step, no host round trip ------------
  * RPN.predict_proposals (detectron2 proposal_utils.find_top_rpn_proposals, called from detectron2_det/__init__.py:74 via the
  * model forward): per FPN level the k best objectness logits (torch.topk(sorted=True); ties: lower anchor index first) and

@@ -132,3 +132,23 @@ def test_wire_kernel_equals_the_torch_sequence(hflip):
     xywh_g, score_g, c_g = detections_to_wire(boxes, scores, classes, W, H)
     xywh, score, c = detections_to_wire(boxes.cpu(), scores.cpu(), classes.cpu(), W, H)
     assert torch.equal(xywh_g.cpu(), xywh) and torch.equal(score_g.cpu(), score) and torch.equal(c_g.cpu(), c)
+
+
+@pytest.mark.parametrize('m,n,k', [(9600, 1024, 1024), (38400, 512, 512), (2400, 2048, 2048), (37, 24, 16)])
+def test_gemm_lt_residual_bias_relu(m, n, k):
+    """wd_gemm_lt_f32: relu(a @ w.T + residual + bias) in one hipBLASLt launch, in place on the residual buffer."""
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn((m, k), generator=g).cuda()
+    w = (torch.randn((n, k), generator=g) / k ** 0.5).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    res = torch.randn((m, n), generator=g).cuda()
+    want = torch.relu(a.double() @ w.double().t() + res.double() + bias.double())
+    buf = res.clone()
+    got = ops.gemm_lt(a, w, bias, buf, True, out=buf)
+    assert got.data_ptr() == buf.data_ptr()
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    got2 = ops.gemm_lt(a, w, bias, res, False)                  # out of place, no ReLU; second call takes the cached plan
+    np.testing.assert_allclose(got2.cpu().double().numpy(), (a.double() @ w.double().t() + res.double() + bias.double()).cpu().numpy(),
+                               rtol=2e-4, atol=2e-4)
+    got3 = ops.gemm_lt(a, w, None, None, False)
+    np.testing.assert_allclose(got3.cpu().double().numpy(), (a.double() @ w.double().t()).cpu().numpy(), rtol=2e-4, atol=2e-4)

@@ -45,6 +45,7 @@ class Conv1x1(nn.Module):
     (tools/gemm_bench.py), ahead of the hand-written wd_gemm_nt_f32 which is kept for the box-head FC.  The residual
     rides on the GEMM's beta term (addmm), bias+ReLU on the library epilogue where there is no residual."""
     USE_LIBRARY_GEMM = True
+    FUSED_RESIDUAL = True
 
     def __init__(self, cin, cout, gen, bn_scale=1.0, bias=False):
         super().__init__()
@@ -77,8 +78,13 @@ class Conv1x1(nn.Module):
         else:
             # inference: the residual buffer is dead after this block (block input or a fresh shortcut output), so the
             # GEMM accumulates into it in place (beta = 1, C == D) - no copy of the residual into a new output
-            y = r.addmm_(a, self.weight.t()) if r.is_contiguous() else torch.addmm(r, a, self.weight.t())
-            y = ops.bias_relu_(y, self.bias, relu)
+            if self.FUSED_RESIDUAL and a.is_contiguous():
+                # residual on the beta term, folded-BN shift + ReLU on the library epilogue: one launch (wd_gemm_lt_f32)
+                y = ops.gemm_lt(a, self.weight, self.bias, r if r.is_contiguous() else r.contiguous(), relu,
+                                out=r if r.is_contiguous() else None)
+            else:
+                y = r.addmm_(a, self.weight.t()) if r.is_contiguous() else torch.addmm(r, a, self.weight.t())
+                y = ops.bias_relu_(y, self.bias, relu)
         return y.view(n, h, w, -1).permute(0, 3, 1, 2)
 
 

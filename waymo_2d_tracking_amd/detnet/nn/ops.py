@@ -218,6 +218,26 @@ def conv3x3_few(x, w2, bias, n_out, stride=1):
     return out
 
 
+_LT_WS = {}
+
+
+def gemm_lt(a, weight, bias=None, residual=None, relu=False, out=None):
+    """out = relu?(a @ weight.T + residual + bias) as ONE hipBLASLt GEMM (beta term + RELU_BIAS epilogue, wd_gemm_lt_f32).
+    a (M,K), weight (N,K), residual / out (M,N) float32 contiguous; `out` may be the residual buffer (in place)."""
+    m, k = a.shape
+    n = weight.shape[0]
+    assert a.is_contiguous() and weight.is_contiguous() and weight.shape[1] == k
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    assert out.is_contiguous() and (residual is None or residual.is_contiguous())
+    ws = _LT_WS.get(a.device)
+    if ws is None:
+        ws = _LT_WS[a.device] = torch.empty(64 << 20, dtype=torch.uint8, device=a.device)
+    _lib.check(_lib.lib().wd_gemm_lt_f32(_p(a), _p(weight), _p(bias), _p(residual), _p(out), C.c_int(m), C.c_int(n), C.c_int(k),
+                                         C.c_int(1 if relu else 0), _p(ws), C.c_size_t(ws.numel()), _stream()), 'wd_gemm_lt_f32')
+    return out
+
+
 SCALE_CLAMP = 4.135166556742356          # log(1000 / 16), Box2BoxTransform
 
 
