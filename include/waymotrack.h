@@ -255,6 +255,21 @@ int wt_ensemble_groups_dev(const double* dets5, const int64_t* group_offsets, co
                            double iou_thresh, double soft_nms_cut, double* out5, int64_t* out_counts,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* --- Waymo Open Dataset protobuf emit (csrc/waymo_proto.hip; host code) -----------------------------------
+ * metrics.Objects - and with submission != 0 the Submission envelope around it - written straight from columns: replaces
+ * the per-object message building of /root/reference/coco_to_waymo.py:16-82 (create_pd_object / create_pb_submission) and
+ * generate_prediction_for_metrics.py:43-80 (metrics_mode = 1: explicit zero z / height / heading, num_lidar_points_in_box =
+ * 100).  context / id: UTF-8 blob + n+1 offsets; has_id NULL = every row has an id when id_offsets is given; score NULL = not
+ * set (ground truth); det_level / trk_level NULL or 0 = not set; authors = n_authors NUL-terminated strings back to back.
+ * Field numbers are recalled from the public waymo-open-dataset .proto files (the package is not in the image). */
+int wt_waymo_objects_write(const char* path, int64_t n, const char* context_blob, const int64_t* context_offsets,
+                           const int64_t* frame_timestamp_micros, const int32_t* camera_name, const double* bbox_xywh,
+                           const double* score, const int32_t* label_type, const char* id_blob, const int64_t* id_offsets,
+                           const uint8_t* has_id, const int32_t* det_level, const int32_t* trk_level, int metrics_mode,
+                           int submission, int task, const char* account_name, const char* unique_method_name,
+                           const char* authors, int n_authors, const char* affiliation, const char* description,
+                           int sensor_type, int64_t* bytes_written);
+
 #ifdef __cplusplus
 }
 #endif

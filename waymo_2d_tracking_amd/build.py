@@ -24,6 +24,7 @@ COMMON += os.environ.get('WD_HIPCC_FLAGS', '').split()          # experiments (e
 UNITS = {
     'api.hip': [],
     'json_io.hip': [],
+    'waymo_proto.hip': [],
     'ensemble.hip': ['-ffp-contract=off'],
     'sort_engine.hip': ['-ffp-contract=off'],
     'sort_single.hip': ['-ffp-contract=off'],
