@@ -88,7 +88,7 @@ class DetectTrackPipeline(object):
         self.tracker = StreamingTracker(n_cameras, SLOTS, self.n_frames, n, list(iou_threshold), max_age, min_hits,
                                         list(score_threshold), device=self.dev)
         self.track_stream = torch.cuda.Stream(device=self.dev)
-        self._prev_done = None
+        self._slot_done = [None] * R      # per ring slot: event of the track() that last read it
         self.chunk = 0                 # chunks of the current segment processed so far
         self.time = 0                  # frame time index into self.frames
         self.segments_done = 0
@@ -156,10 +156,10 @@ class DetectTrackPipeline(object):
             self.chunk = 0
             self.segments_done += 1
         c = self.chunk
-        if self._prev_done is not None:
-            # slots of chunk c may still be read by a track() of the previous segment: it was queued before the most
-            # recent one on the same in-order stream, so waiting for that one covers it
-            main.wait_event(self._prev_done)
+        if self._slot_done[c] is not None:
+            # the slots of ring position c were last read by the track() of the previous segment's chunk c (a whole segment
+            # ago): wait for THAT call only - waiting for the most recent track() would serialise SORT and the detector
+            main.wait_event(self._slot_done[c])
         for cam in range(self.nc):
             for j in range(self.fpc):
                 self.detect_frame(c, cam, j, eager=(instrument and cam == 0 and j == 0))
@@ -169,8 +169,8 @@ class DetectTrackPipeline(object):
             with torch.cuda.stream(self.track_stream):
                 self.track_stream.wait_event(filled)             # slots of this chunk are complete
                 self.track(c)                                    # SORT of chunk c runs under the detector pass of chunk c + 1
-                self._prev_done = torch.cuda.Event()
-                self._prev_done.record(self.track_stream)
+                self._slot_done[c] = torch.cuda.Event()
+                self._slot_done[c].record(self.track_stream)
         self.chunk += 1
         self.time = (self.time + self.fpc) % self.n_times
         return None
