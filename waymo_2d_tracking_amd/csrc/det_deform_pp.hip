@@ -288,7 +288,11 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     const unsigned patch_b0 = (unsigned)((char*)patch_t - smem);          // LDS byte offset of this team's buffer 0
     const unsigned kx = (unsigned)(2 * kq) << 4;            // byte XOR selecting this lane's first quad
     const char* lds = smem;
+#ifdef PP_LIN_ENTRY
+    const uint4* my_tab = tab_t + r16 * 9;      // experiments: conflict-free entry reads (wrong pixels)
+#else
     const uint4* my_tab = tab_t + my_p * 9;
+#endif
     const float* my_bw = bw + lane * 4;
 
     auto read_entry = [&](int k) { ent = my_tab[k]; };                    // LDS
@@ -301,6 +305,9 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         ad1 = ((ent.x >> 16) ^ kx) + base;
         ad2 = ((ent.y & 0xFFFFu) ^ kx) + base;
         ad3 = ((ent.y >> 16) ^ kx) + base;
+#ifdef PP_LIN_CORNER
+        ad0 = base + lane * 32; ad1 = ad0 + 2048; ad2 = ad0 + 4096; ad3 = ad0 + 6144;      // experiments: lane-linear corner reads
+#endif
     };
     auto issue_reads = [&](int k, float4 (&bb)[4]) {                      // LDS: corners of the prepared tap + weights of tap k
         cv[0] = *reinterpret_cast<const float4*>(lds + ad0); cv[1] = *reinterpret_cast<const float4*>(lds + (ad0 ^ 16));
