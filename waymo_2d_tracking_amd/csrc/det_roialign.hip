@@ -240,17 +240,64 @@ __global__ __launch_bounds__(256) void roi_pool_sep_kernel(Levels lv, int n_leve
 // channels (1 KiB, the whole pixel for C = 256), 4x fewer instructions per byte than the dword version above.  The
 // wave builds WY[ph][.] and WX[0..6][.] itself (lanes 0..7, sequential sums: deterministic), walks the footprint rows of
 // its bin row once with 16 x 1 KiB loads in flight, and writes the 7 x C outputs of (ROI, ph) as one contiguous run.
+// Processing order of the ROIs: by FPN level, then by 16-pixel rows of the level's feature map, then by x.  One workgroup,
+// bitonic sort of (key << 32 | index) in LDS (n <= 8192).  Only the ORDER of the work changes - outputs stay in ROI order.
+__global__ __launch_bounds__(1024) void roi_order_kernel(Levels lv, int n_levels, const float* __restrict__ rois, int n_rois,
+                                                        int min_level, int canonical_level, float canonical_size,
+                                                        int* __restrict__ order) {
+    extern __shared__ unsigned long long okeys[];
+    int p = 2;
+    while (p < n_rois) p <<= 1;
+    for (int t = threadIdx.x; t < p; t += 1024) {
+        unsigned long long key = ~0ull;
+        if (t < n_rois) {
+            const float* roi = rois + 5 * (size_t)t;
+            const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+            const float size = sqrtf((x2 - x1) * (y2 - y1));
+            int lvl = (int)floorf((float)canonical_level + log2f(size / canonical_size + 1e-8f));
+            lvl = lvl < min_level ? min_level : (lvl > min_level + n_levels - 1 ? min_level + n_levels - 1 : lvl);
+            const int li = lvl - min_level;
+            const float sc = lv.scale[li];
+            float cx = 0.5f * (x1 + x2) * sc, cy = 0.5f * (y1 + y2) * sc;
+            cx = cx > 0.f ? (cx < 8191.f ? cx : 8191.f) : 0.f;        // NaN -> 0
+            cy = cy > 0.f ? (cy < 8191.f ? cy : 8191.f) : 0.f;
+            const unsigned k = ((unsigned)li << 26) | (((unsigned)cy >> 4) << 13) | (unsigned)cx;
+            key = ((unsigned long long)k << 32) | (unsigned)t;
+        }
+        okeys[t] = key;
+    }
+    for (int size = 2; size <= p; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (p >> 1); t += 1024) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const unsigned long long a = okeys[i], b = okeys[j];
+                const bool asc = (i & size) == 0;
+                if ((a > b) == asc) { okeys[i] = b; okeys[j] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_rois; t += 1024) order[t] = (int)(okeys[t] & 0xffffffffull);
+}
+
 __global__ __launch_bounds__(256) void roi_pool_row_kernel(Levels lv, int n_levels, int C, int batch,
                                                            const float* __restrict__ rois, int n_rois,
                                                            int min_level, int canonical_level, float canonical_size,
-                                                           float* __restrict__ out, int* __restrict__ fallback_flags) {
+                                                           float* __restrict__ out, int* __restrict__ fallback_flags,
+                                                           const int* __restrict__ order) {
     __shared__ float tabs[4][8][kMaxFoot];          // per wave: [0] = WY[ph], [1 + pw] = WX[pw]
     __shared__ int lohi[4][8][2];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int unit = blockIdx.x * 4 + wave;
-    if (unit >= n_rois * 7) return;
-    const int r = unit / 7, ph = unit - 7 * r;
+    // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each with its own L2: give every XCD a CONTIGUOUS eighth
+    // of the (spatially sorted) unit list, so that ROIs overlapping in the feature maps meet in one L2 at about the same time
+    const int per_xcd = ((int)gridDim.x + 7) >> 3;
+    const int block = order ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int unit = block * 4 + wave;
+    if (unit >= n_rois * 7 || (order && block >= ((n_rois * 7 + 3) >> 2))) return;
+    const int slot = unit / 7, ph = unit - 7 * slot;
+    const int r = order ? order[slot] : slot;
     float (*tab)[kMaxFoot] = tabs[wave];
     const float* roi = rois + 5 * (size_t)r;
     const int b = (int)roi[0];
@@ -389,13 +436,25 @@ extern "C" int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* hei
     if (pooled == 7) {
         if (flags_cap < n_rois) {
             if (flags) (void)hipFree(flags);
-            WT_HIP(hipMalloc(&flags, sizeof(int) * (size_t)n_rois * 2));
+            WT_HIP(hipMalloc(&flags, sizeof(int) * (size_t)n_rois * 4));          // [fallback flags | processing order]
             flags_cap = n_rois * 2;
+        }
+        int* order = nullptr;
+        // WD_ROI_ORDER=1: spatially sorted processing order + one contiguous eighth of it per XCD.  Measured on MI355X (1000 ROIs,
+        // profiles/r02_hbm_rooflines_roi_ordered.json): L2->fabric fetch traffic 375 -> 184 MB (the unique footprint is 136 MB), but
+        // 105 -> 124 us: at this size the kernel is bound by load latency / occupancy (27 waves per CU in total), not by HBM
+        // bytes, and the sort adds a launch.  Off by default.
+        const char* om = getenv("WD_ROI_ORDER");
+        if (n_rois >= 64 && n_rois <= 8192 && om && om[0] == '1') {
+            order = flags + flags_cap;
+            hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), (size_t)8192 * 8, (hipStream_t)stream, lv, n_levels, rois,
+                               n_rois, min_level, canonical_level, canonical_size, order);
         }
         const char* mode = getenv("WD_ROI_KERNEL");             // experiments: "sep" = one workgroup per ROI
         if ((channels & 3) == 0 && ((uintptr_t)out & 15) == 0 && !(mode && strcmp(mode, "sep") == 0))
-            hipLaunchKernelGGL(roi_pool_row_kernel, dim3((unsigned)((n_rois * 7 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, lv,
-                               n_levels, channels, batch, rois, n_rois, min_level, canonical_level, canonical_size, out, flags);
+            hipLaunchKernelGGL(roi_pool_row_kernel, dim3((unsigned)(order ? (((n_rois * 7 + 3) / 4 + 7) / 8 * 8) : (n_rois * 7 + 3) / 4)),
+                               dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels, batch, rois, n_rois, min_level,
+                               canonical_level, canonical_size, out, flags, (const int*)order);
         else
             hipLaunchKernelGGL(roi_pool_sep_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
                                channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out, flags);
