@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument('--collate', action='store_true',
                     help='e2e: gather every chunk\'s track rows to rank 0 inside the timed region (the submission collation over RCCL)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--inflight', type=int, default=1,
+                    help='e2e/detect: frames in flight (hipGraph lanes on separate streams); EXPERIMENT: 2 deadlocks at 1920x1280 (spin-waiting library kernels)')
     ap.add_argument('--no-graph', action='store_true', help='e2e/detect: launch every frame eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--no-verify', action='store_true', help='skip the oracle replay of the timed output (after the timed region)')
     return ap.parse_args()

@@ -43,7 +43,7 @@ def moving_frames(n_cameras, n_times, height, width, seed, device):
 class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
                  iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta='',
-                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True):
+                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True, n_inflight=1):
         self.dev = torch.device(device)
         # --tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image, folded into the pre-processing kernel
         self.tta_scale, self.tta_hflip = 1.0, False
@@ -72,6 +72,7 @@ class DetectTrackPipeline(object):
         self.category = torch.zeros((R, n), dtype=torch.int32, device=self.dev)
         self.n_dets_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.use_graph, self._graph = use_graph, None
+        self.n_inflight, self._lanes, self._frame_no = max(1, n_inflight), [], 0
         # per-chunk tracker output rows
         self.out_frame = torch.zeros((R, n + 1), dtype=torch.int64, device=self.dev)
         self.out_cat = torch.zeros((R, n + 1), dtype=torch.int32, device=self.dev)
@@ -108,39 +109,60 @@ class DetectTrackPipeline(object):
         return xywhs, cat, cnt
 
     def _capture(self):
-        """Warm up eagerly (MIOpen / TunableOp pick their kernels), then capture the whole per-frame detector as one hipGraph."""
-        from .detnet.nn import ops
+        """Per lane: warm up eagerly on the lane's stream (MIOpen / TunableOp / hipBLASLt pick their kernels, per-stream scratch
+        gets allocated), then capture the whole per-frame detector as one hipGraph on that stream.  Every lane owns its input /
+        output / intermediate buffers, so the graphs of consecutive frames could be in flight at the same time (the serial tails
+        of one frame under the other frame's GEMMs).  n_inflight = 1 is the default and the only supported setting at full
+        size: two 1920x1280 detector graphs in flight DEADLOCK on MI355X (measured, round 2) - library kernels that spin on
+        partner workgroups need all of them resident, which two chip-filling kernels on different streams do not guarantee."""
         saved, ops.EVENT_LOG = ops.EVENT_LOG, None          # no event records inside a capture
-        self._gin = torch.zeros((1, self.h, self.w, 3), dtype=torch.uint8, device=self.dev)
-        side = torch.cuda.Stream(device=self.dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for t in range(3):
-                self._gin.copy_(self.frames[t % self.n_times, 0].unsqueeze(0))
-                self._detect_core(self._gin)
-        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self._graph):
-            self._gout = self._detect_core(self._gin)
+        self._lanes = []
+        for k in range(self.n_inflight):
+            lane = dict(stream=torch.cuda.Stream(device=self.dev), n_dets=torch.zeros(1, dtype=torch.int64, device=self.dev),
+                        gin=torch.zeros((1, self.h, self.w, 3), dtype=torch.uint8, device=self.dev))
+            with torch.cuda.stream(lane['stream']), torch.no_grad():
+                for t in range(3):
+                    lane['gin'].copy_(self.frames[t % self.n_times, 0].unsqueeze(0))
+                    self._detect_core(lane['gin'])
+            lane['stream'].synchronize()
+            lane['graph'] = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream']):
+                lane['gout'] = self._detect_core(lane['gin'])
+            self._lanes.append(lane)
+        torch.cuda.synchronize()
+        self._graph = self._lanes[0]['graph']
         ops.EVENT_LOG = saved
 
     def detect_frame(self, c, cam, j, eager=False):
         """Frame j of camera cam of chunk c -> wire-format detections in that frame's 100 slots."""
         # decoded uint8 HWC RGB frame -> fused pre-processing kernel (ToTensor(scaling=False) + BGR + normalise + pad)
         img = self.frames[(self.time + j) % self.n_times, cam].unsqueeze(0)
-        if self.use_graph and not eager:
-            if self._graph is None:
-                self._capture()
-            self._gin.copy_(img)
-            self._graph.replay()
-            xywhs, cat, cnt = self._gout
-        else:
-            xywhs, cat, cnt = self._detect_core(img)
         a = (cam * self.fpc + j) * SLOTS
-        self.xywhs[c, :, a:a + SLOTS] = xywhs
-        self.category[c, a:a + SLOTS] = cat
-        self.n_dets_dev += cnt
+        if not self.use_graph:
+            xywhs, cat, cnt = self._detect_core(img)
+            self.xywhs[c, :, a:a + SLOTS] = xywhs
+            self.category[c, a:a + SLOTS] = cat
+            self.n_dets_dev += cnt
+            return
+        if self._graph is None:
+            self._capture()
+        lane = self._lanes[self._frame_no % self.n_inflight]
+        self._frame_no += 1
+        with torch.cuda.stream(lane['stream']):
+            if eager:
+                xywhs, cat, cnt = self._detect_core(img)
+            else:
+                lane['gin'].copy_(img)
+                lane['graph'].replay()
+                xywhs, cat, cnt = lane['gout']
+            self.xywhs[c, :, a:a + SLOTS] = xywhs
+            self.category[c, a:a + SLOTS] = cat
+            lane['n_dets'] += cnt
+
+    @property
+    def n_dets_total(self):
+        return int(self.n_dets_dev.item()) + sum(int(l['n_dets'].item()) for l in getattr(self, '_lanes', []))
 
     def track(self, c):
         self.tracker.feed(self.x[c], self.y[c], self.wd[c], self.ht[c], self.score[c], self.category[c], self.frame_off,
@@ -156,18 +178,35 @@ class DetectTrackPipeline(object):
             self.chunk = 0
             self.segments_done += 1
         c = self.chunk
+        streams = [l['stream'] for l in self._lanes] if (self.use_graph and self._lanes) else []
         if self._slot_done[c] is not None:
             # the slots of ring position c were last read by the track() of the previous segment's chunk c (a whole segment
             # ago): wait for THAT call only - waiting for the most recent track() would serialise SORT and the detector
             main.wait_event(self._slot_done[c])
+            for st in streams:
+                st.wait_event(self._slot_done[c])
+        if self.use_graph and self._graph is None:
+            self._capture()
+            streams = [l['stream'] for l in self._lanes]
+        start = torch.cuda.Event()
+        start.record(main)
+        for st in streams:
+            st.wait_event(start)                                 # lanes never run ahead of work queued on the caller's stream
         for cam in range(self.nc):
             for j in range(self.fpc):
-                self.detect_frame(c, cam, j, eager=(instrument and cam == 0 and j == 0))
+                self.detect_frame(c, cam, j, eager=(instrument and cam == self.nc - 1 and j == self.fpc - 1))
+        done = []
+        for st in streams:                                       # no join on the caller's stream: the next step's frames may start
+            ev = torch.cuda.Event()                              # while this step's last ones finish (callers synchronise the
+            ev.record(st)                                        # device before reading results)
+            done.append(ev)
         if with_tracking:
             filled = torch.cuda.Event()
             filled.record(main)
             with torch.cuda.stream(self.track_stream):
-                self.track_stream.wait_event(filled)             # slots of this chunk are complete
+                self.track_stream.wait_event(filled)             # slots of this chunk are complete (eager path)
+                for ev in done:
+                    self.track_stream.wait_event(ev)             # ... on every lane
                 self.track(c)                                    # SORT of chunk c runs under the detector pass of chunk c + 1
                 self._slot_done[c] = torch.cuda.Event()
                 self._slot_done[c].record(self.track_stream)
@@ -266,7 +305,7 @@ def _pmc_traffic(tag):
 def run(args, world, rank, timed_steps):
     from .detnet.nn import ops
     fps = max(1, args.frames_per_step // 5)
-    pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False))
+    pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False), n_inflight=getattr(args, 'inflight', 1))
     steps = args.steps or 3
     warmup = args.warmup if args.warmup is not None else 1
     track = args.stage == 'e2e'
@@ -277,8 +316,9 @@ def run(args, world, rank, timed_steps):
         if state['n'] == warmup:
             ops.EVENT_LOG = []
         state['n'] += 1
-        # frame 0 of every timed step runs eagerly so that its deform-conv launches carry HIP events; the other frames replay
-        # the captured hipGraph of the same launches
+        # the LAST frame of every timed step runs eagerly so that its deform-conv launches carry HIP events (the first frames of a
+        # step share the chip with the SORT kernel of the previous chunk); the other frames replay the captured hipGraph of the
+        # same launches
         pipe.step(track, instrument=ops.EVENT_LOG is not None)
         if track and getattr(args, 'collate', False):
             got = pipe.collate_last_chunk()
@@ -314,7 +354,7 @@ def run(args, world, rank, timed_steps):
                         % (', --tta ' + args.tta if getattr(args, 'tta', '') else '',
                            'SORT (max_age 2, min_hits 0, all boxes tracked; trackers resident for the whole segment)' if track else 'no tracking', 5, fps),
                roofline=roofline,
-               extra=dict(frames_per_step=frames, dets_per_frame=float(pipe.n_dets_dev.item()) / max(1, frames * state['n']), hip_graph=pipe._graph is not None, track_rows=n_out, births=births,
+               extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_total / max(1, frames * state['n']), hip_graph=pipe._graph is not None, track_rows=n_out, births=births,
                           collated_rows_rank0=state.get('collated_rows')))
     res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters
     return res, steps, warmup

@@ -17,6 +17,9 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 #include "../../include/waymodet.h"
 
 namespace {
@@ -431,14 +434,26 @@ extern "C" int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* hei
     for (int i = 0; i < n_levels; ++i) { lv.feat[i] = feats[i]; lv.h[i] = heights[i]; lv.w[i] = widths[i]; lv.scale[i] = scales[i]; }
     // The separable kernel handles ROIs whose footprint fits 64 x 64 feature pixels (all but degenerate whole-image
     // boxes); it flags the rest, which the direct kernel then processes (it exits immediately for unflagged ROIs).
-    static thread_local int* flags = nullptr;
-    static thread_local int flags_cap = 0;
+    // scratch ([fallback flags | processing order]) per stream: launches on different streams may be in flight concurrently
+    // (two frames' graphs), and a buffer baked into a captured graph must stay valid -> buffers are never freed or moved;
+    // a stream that later needs more rows gets an additional, larger buffer
+    struct Scratch { int* p; int rows; };                        // 4 * rows ints: flags [0, 2 rows), order [2 rows, 3 rows)
+    static std::mutex mu;
+    static std::unordered_map<void*, std::vector<Scratch>> scratch;
+    int* flags = nullptr;
+    int flags_cap = 0;
     if (pooled == 7) {
-        if (flags_cap < n_rois) {
-            if (flags) (void)hipFree(flags);
-            WT_HIP(hipMalloc(&flags, sizeof(int) * (size_t)n_rois * 4));          // [fallback flags | processing order]
-            flags_cap = n_rois * 2;
+        std::lock_guard<std::mutex> lock(mu);
+        auto& list = scratch[stream];
+        int rows = 0;
+        for (const Scratch& sc : list)
+            if (sc.rows >= n_rois) { flags = sc.p; rows = sc.rows; break; }
+        if (!flags) {
+            WT_HIP(hipMalloc(&flags, sizeof(int) * (size_t)n_rois * 4));        // (not inside a stream capture: warm up first)
+            rows = n_rois;
+            list.push_back({flags, rows});
         }
+        flags_cap = 2 * rows;
         int* order = nullptr;
         // WD_ROI_ORDER=1: spatially sorted processing order + one contiguous eighth of it per XCD.  Measured on MI355X (1000 ROIs,
         // profiles/r02_hbm_rooflines_roi_ordered.json): L2->fabric fetch traffic 375 -> 184 MB (the unique footprint is 136 MB), but

@@ -230,9 +230,10 @@ def gemm_lt(a, weight, bias=None, residual=None, relu=False, out=None):
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     assert out.is_contiguous() and (residual is None or residual.is_contiguous())
-    ws = _LT_WS.get(a.device)
+    key = (a.device, torch.cuda.current_stream().cuda_stream)       # one workspace per stream: frames may be in flight concurrently
+    ws = _LT_WS.get(key)
     if ws is None:
-        ws = _LT_WS[a.device] = torch.empty(64 << 20, dtype=torch.uint8, device=a.device)
+        ws = _LT_WS[key] = torch.empty(64 << 20, dtype=torch.uint8, device=a.device)
     _lib.check(_lib.lib().wd_gemm_lt_f32(_p(a), _p(weight), _p(bias), _p(residual), _p(out), C.c_int(m), C.c_int(n), C.c_int(k),
                                          C.c_int(1 if relu else 0), _p(ws), C.c_size_t(ws.numel()), _stream()), 'wd_gemm_lt_f32')
     return out

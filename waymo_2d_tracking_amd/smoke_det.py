@@ -9,7 +9,7 @@ def run(track_streams=None):
     for _ in range(3):
         pipe.step(True)
     torch.cuda.synchronize()
-    n = int(pipe.n_dets_dev.item())
+    n = pipe.n_dets_total
     n_out, births = [int(v) for v in pipe.counts.cpu().tolist()]
     assert n_out >= 0, 'SORT kernel status %d' % -n_out
     if track_streams is not None:
