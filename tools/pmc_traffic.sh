@@ -7,12 +7,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --kernel-trace --output-format csv -d /tmp/prof_pmc -- python3 $R/tools/deform_one.py > /tmp/prof_pmc.log 2>&1
 python3 - "$(find /tmp/prof_pmc -name '*counter_collection.csv' | head -1)" $OUT/pmc_traffic.json <<'PY'
-import csv, json, sys, collections
+import csv, json, re, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Kernel_Name']
     if 'deform_conv3x3' in n:
-        key = n.split('(')[0].replace('void (anonymous namespace)::', '')
+        key = re.search(r'deform_conv3x3\w*(<[^>]*>)?', n).group(0)
         acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {}
 for k, d in acc.items():

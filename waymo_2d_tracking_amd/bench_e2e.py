@@ -291,14 +291,15 @@ def _pmc_traffic(tag):
     """HBM bytes per launch of the roofline kernel from the committed PMC pass (profiles/r01_e2e_pmc_traffic.json,
     collected with tools/pmc_traffic.sh - counters cannot be read from inside the timed run); None if not recorded."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r01_e2e_pmc_traffic.json')
-    try:
-        rec = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    for name, v in rec.items():
-        if tag.startswith(name):
-            return v.get('traffic_bytes_per_launch')
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+    for fname in ('r02_e2e_pmc_traffic.json', 'r01_e2e_pmc_traffic.json'):
+        try:
+            rec = json.load(open(os.path.join(root, fname)))
+        except (OSError, ValueError):
+            continue
+        for name, v in rec.items():
+            if tag.startswith(name):
+                return v.get('traffic_bytes_per_launch')
     return None
 
 

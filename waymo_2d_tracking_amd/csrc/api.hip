@@ -45,7 +45,7 @@ extern "C" {
 
 const char* wt_last_error(void) { return wt::g_err; }
 
-int wt_abi_version(void) { return 3; }   // 3: streaming tracker (wt_track_state_* / wt_track_chunk_dev / wt_track_global_ids_dev);   // 2: wd_deform_im2col/col2im take `groups` (group-major columns); new wd_preprocess / wd_decode_boxes / wd_tap_shift_add / wt_mct entry points
+int wt_abi_version(void) { return 4; }   // 4: static-shape detector tail (wd_rpn_topk_decode / wd_sort_candidates / wd_box_candidates / wd_gather_kept / wd_detections_to_wire), wd_gemm_lt, wt_detjson_*, wt_waymo_objects_write;   // 3: streaming tracker (wt_track_state_* / wt_track_chunk_dev / wt_track_global_ids_dev);   // 2: wd_deform_im2col/col2im take `groups` (group-major columns); new wd_preprocess / wd_decode_boxes / wd_tap_shift_add / wt_mct entry points
 
 int wt_device_info(int* n_devices, char* arch, int arch_cap, int* n_cu) {
     int n = 0;
