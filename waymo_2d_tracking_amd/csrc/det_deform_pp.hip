@@ -23,7 +23,7 @@
 //   * four independent accumulator chains (a dependent MFMA pair 64 cycles apart measured 39 instead of 32 cycles per MFMA);
 //   * D = W x samples (weights are the A operand): a lane ends up with 4 consecutive output channels of its pixel -> the
 //     epilogue (FrozenBN affine + ReLU) writes 16 bytes per lane and 16-channel tile.
-// LDS: 36 864 (weights) + 4 x 25 216 (patches) + 2 x 9 216 (tables) + 256 (affine) = 156 416 bytes.
+// LDS: 36 864 (weights) + 4 x 25 216 (patches) + 2 x 9 344 (tables) + 256 (affine) = 156 672 bytes.
 #include <type_traits>
 #include "common.h"
 #include "../../include/waymodet.h"
@@ -40,7 +40,8 @@ constexpr int PATCH_F = (NPIX + 1) * CG;   // floats per patch buffer
 constexpr int NE = 64 * 9;             // (pixel, tap) entries per tile
 constexpr int BW_F = 9 * 4 * 64 * 4;   // weights of one group: [tap][j][lane][4]
 constexpr float FAR = 2.0f;            // lh >= FAR flags a sample whose corners are outside the patch
-constexpr size_t SMEM = (size_t)BW_F * 4 + 4 * (size_t)PATCH_F * 4 + 2 * (size_t)NE * 16 + 256;
+constexpr int NT = NE + 8;              // table slots: the entries of tile rows 4-7 sit 8 slots (128 B) further, see tab_slot()
+constexpr size_t SMEM = (size_t)BW_F * 4 + 4 * (size_t)PATCH_F * 4 + 2 * (size_t)NT * 16 + 256;
 }  // namespace pp
 
 // Workgroup barrier without the fence of __syncthreads(): the fence makes every wave wait for its outstanding LDS READS
@@ -69,6 +70,14 @@ __device__ __forceinline__ int pp_row_pixel(int r, int m) {
     return y * 8 + x;
 }
 
+// Table slot of entry e = pixel * 9 + tap.  A wave reads the entries of tile rows m and m + 4 in one ds_read_b128: their pitch of 9
+// slots maps both rows onto the same 8 of the 16 slots of a 256-byte bank row; 8 extra slots for rows 4-7 make it conflict-free.
+#ifdef PP_TAB_PAD
+__device__ __forceinline__ int pp_tab_slot(int e) { return e + (e >= 32 * 9 ? 8 : 0); }
+#else
+__device__ __forceinline__ int pp_tab_slot(int e) { return e; }      // measured: the padded table removes the 2-way conflict of the entry read (10 % -> 4 % of LDS cycles) and changes nothing in time
+#endif
+
 // 16-byte slot index of quad q (0..7) of patch pixel p
 __device__ __forceinline__ int pp_slot(int p, int q) { return (p << 3) + (q ^ ((p >> 1) & 7)); }
 
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     float* bw = reinterpret_cast<float*>(smem);
     float* patch_all = bw + pp::BW_F;
     uint4* tab_all = reinterpret_cast<uint4*>(patch_all + 4 * pp::PATCH_F);
-    float* affine = reinterpret_cast<float*>(tab_all + 2 * pp::NE);          // [scale 32][bias 32]
+    float* affine = reinterpret_cast<float*>(tab_all + 2 * pp::NT);          // [scale 32][bias 32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: scalar branches on team / slot
     const int team = wave >> 2, m = wave & 3, tt = tid & 255;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     const int t1 = t0 + tq + (sidx < trm ? 1 : 0);
     const int n_items = (t1 - t0 + 1) >> 1;                 // per team (the last one of team 1 may be a dummy)
     float* patch_t = patch_all + team * 2 * pp::PATCH_F;
-    uint4* tab_t = tab_all + team * pp::NE;
+    uint4* tab_t = tab_all + team * pp::NT;
     const int c0 = g * pp::CG;
     const long HW = (long)H * W;
     const char* xb = reinterpret_cast<const char*>(x);
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     auto write_table = [&]() {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            if (t_yx[j] != 0xFFFF) tab_t[tt + 256 * j] = tent[j];
+            if (t_yx[j] != 0xFFFF) tab_t[pp_tab_slot(tt + 256 * j)] = tent[j];
     };
     auto build_table = [&](const TileXY& T) {
         compute_entry(T, 0); compute_entry(T, 1); compute_entry(T, 2);
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
 #ifdef PP_LIN_ENTRY
     const uint4* my_tab = tab_t + r16 * 9;      // experiments: conflict-free entry reads (wrong pixels)
 #else
-    const uint4* my_tab = tab_t + my_p * 9;
+    const uint4* my_tab = tab_t + pp_tab_slot(my_p * 9);
 #endif
     const float* my_bw = bw + lane * 4;
 
