@@ -211,3 +211,27 @@ def test_detect_track_pipeline_vs_oracle(oracle):
     pipe.step(True); pipe.step(True)    # wrap: new segment, chunks 1-2
     rep = check_against(pipe, oracle.track_streams)
     assert rep['ok'] and rep['chunks'] == 2 and pipe.segments_done == 1, rep
+
+
+def test_graph_replay_equals_eager_launches():
+    """The captured per-frame hipGraph and the same frame launched eagerly fill the same slots (the timed path replays the
+    graph; the oracle checks above see only what the slots hold), with TTA folded in as well.  The library convolutions
+    MIOpen picks accumulate split-K partial sums with atomics, so two runs of the SAME launches differ in the last float bits and
+    the random-init detector's near-tied scores may then order two detections differently: the test asks for the same number
+    of detections and > 90 % bit-identical slot values (a replay reading stale inputs or buffers gives ~0 %)."""
+    import torch
+    from waymo_2d_tracking_amd.bench_e2e import DetectTrackPipeline
+    for tta in ('', 'x1.5,hflip'):
+        graph = DetectTrackPipeline(n_cameras=2, frames_per_camera=2, height=256, width=384, seed=5, segment_frames=8, distinct_times=4,
+                                    tta=tta)
+        eager = DetectTrackPipeline(n_cameras=2, frames_per_camera=2, height=256, width=384, seed=5, segment_frames=8, distinct_times=4,
+                                    tta=tta, model=graph.model, use_graph=False)
+        for _ in range(2):
+            graph.step(True)
+            eager.step(True)
+        torch.cuda.synchronize()
+        assert graph._graph is not None and eager._graph is None
+        assert int((graph.category[:2] != 0).sum()) == int((eager.category[:2] != 0).sum()) > 0
+        assert float((graph.category[:2] == eager.category[:2]).double().mean()) > 0.9
+        assert float((graph.xywhs[:2] == eager.xywhs[:2]).double().mean()) > 0.9
+        assert graph.n_dets_total == eager.n_dets_total
