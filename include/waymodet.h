@@ -45,6 +45,13 @@ int wd_select_kept(const uint8_t* keep_mask, const uint8_t* valid, const int64_t
 int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_threshold,
                       uint8_t* keep_mask, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* wd_gemm_nt_f32 for large shapes (box-head fc1, job.log:1146-1218): 128 x 128 tiles, fragments by ds_read_b128 from an
+ * XOR-swizzled LDS image, deterministic two-pass split-K through `workspace` (wd_gemm_nt_workspace bytes; 0 = the shape runs on
+ * the v1 kernel and needs none). */
+size_t wd_gemm_nt_workspace(int M, int N, int K);
+int wd_gemm_nt_ws_f32(const float* A, const float* Bt, const float* bias, const float* residual, int relu, int M, int N, int K,
+                      float* C, void* workspace, size_t workspace_bytes, void* stream);
+
 /* 1x1 convolution with residual (detectron2 BottleneckBlock conv3 + shortcut + ReLU, job.log:412-415) as ONE hipBLASLt GEMM:
  * out (m, n) = relu?(a (m, k) . w (n, k)^T + residual (m, n) + bias (n)), row-major; residual may alias out.  beta = 1 carries
  * the residual, the RELU_BIAS epilogue the folded FrozenBN shift.  The first call per shape (outside a stream capture) times the

@@ -5,6 +5,7 @@ of libwaymotrack.so on the current stream and raises if the library or a GPU is 
 Feature maps are (N, C, H, W) tensors in ``torch.channels_last`` storage, i.e. NHWC in memory.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -170,8 +171,15 @@ def gemm_nt(a, bt, bias=None, residual=None, relu=False, out=None):
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     if residual is not None:
         residual = residual.contiguous()
-    _lib.check(_lib.lib().wd_gemm_nt_f32(_p(a), _p(bt), _p(bias), _p(residual), C.c_int(1 if relu else 0), C.c_int(m),
-                                         C.c_int(n), C.c_int(k), _p(out), _stream()), 'wd_gemm_nt_f32')
+    lib = _lib.lib()
+    need = int(lib.wd_gemm_nt_workspace(C.c_int(m), C.c_int(n), C.c_int(k)))
+    if need and os.environ.get('WD_GEMM_V1') != '1':       # large shapes (box-head FC): 128x128 tiles, two-pass split-K
+        ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+        _lib.check(lib.wd_gemm_nt_ws_f32(_p(a), _p(bt), _p(bias), _p(residual), C.c_int(1 if relu else 0), C.c_int(m), C.c_int(n),
+                                         C.c_int(k), _p(out), _p(ws), C.c_size_t(need), _stream()), 'wd_gemm_nt_ws_f32')
+        return out
+    _lib.check(lib.wd_gemm_nt_f32(_p(a), _p(bt), _p(bias), _p(residual), C.c_int(1 if relu else 0), C.c_int(m),
+                                  C.c_int(n), C.c_int(k), _p(out), _stream()), 'wd_gemm_nt_f32')
     return out
 
 
