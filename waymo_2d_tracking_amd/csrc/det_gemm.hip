@@ -338,8 +338,9 @@ extern "C" int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias
 extern "C" size_t wd_gemm_nt_workspace(int M, int N, int K) {
     if (M < 256 || N < 256 || K < 1024 || (N & 3) || (K & 31) || (long)M * K >= (1l << 31) || (long)N * K >= (1l << 31)) return 0;
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    static const int target = []() { const char* e = getenv("WD_GEMM_V2_WGS"); return e ? atoi(e) : 448; }();     // experiments
     int splitk = 1;
-    while (tiles * splitk < 448 && K / (splitk * 2) >= 512) splitk *= 2;
+    while (tiles * splitk < target && K / (splitk * 2) >= 512) splitk *= 2;
     return (size_t)splitk * M * N * sizeof(float);
 }
 
