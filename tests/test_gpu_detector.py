@@ -227,7 +227,7 @@ def test_inference_cli_on_image_folder(tmp_path):
     got = I.autocontrast_(torch.from_numpy(np.array(img)).cuda()).cpu().numpy()
     assert np.array_equal(got, np.asarray(ImageOps.autocontrast(img)))
     flat = Image.fromarray(np.full((8, 8, 3), 77, np.uint8))
-    assert np.array_equal(I.autocontrast_(torch.from_numpy(np.asarray(flat)).cuda()).cpu().numpy(), np.asarray(ImageOps.autocontrast(flat)))
+    assert np.array_equal(I.autocontrast_(torch.from_numpy(np.array(flat)).cuda()).cpu().numpy(), np.asarray(ImageOps.autocontrast(flat)))
     out3 = tmp_path / 'sub3.json'
     I.main(['-m', model, '-i', str(root), '--export', str(out3), '--auto-contrast=1'])
     assert json.load(open(out3)) != json.load(open(out))
