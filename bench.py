@@ -107,7 +107,6 @@ def timed_steps(world, run_step, steps, warmup):
 
 def build_predictions(seed, n_segments, n_frames=198, n_objects=100):
     from waymo_2d_tracking_amd import synthetic as syn
-    from waymo_2d_tracking_amd.tracking import utils as T
     rng = np.random.default_rng(seed)
     xs, ys, ws, hs, ss, cs, fo, so, cw, ch = [], [], [], [], [], [], [0], [0], [], []
     n = 0

@@ -11,16 +11,14 @@ Every chunk of the current segment keeps its own detection slots and output rows
 after a run `history()` hands the exact detections the tracker saw and the rows it produced to a checker
 (tests/test_gpu_e2e.py and bench.py replay them through the CPU oracle).
 """
-import ctypes as C
 import os
-import time
 
 import numpy as np
 import torch
 
 from . import _lib
 from .detnet.nn import ops
-from .detnet.nn.detectron2_det import Detectron2Det, detections_to_wire
+from .detnet.nn.detectron2_det import Detectron2Det
 from .devpath import StreamingTracker
 from .tuning import enable_gemm_tuning
 

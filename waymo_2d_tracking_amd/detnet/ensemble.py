@@ -13,7 +13,6 @@ result columns reach rank 0 in one tensor gather (RCCL over xGMI) - no data-path
 """
 import argparse
 import ctypes as C
-import json
 import numbers
 import os
 from pathlib import Path

@@ -16,7 +16,6 @@ tensor gather over RCCL - no files, no collective inside the detection loop.  Im
 dataset workers) runs in a thread pool ahead of the GPU; AutoContrast runs on the GPU.
 """
 import argparse
-import json
 import os
 import time
 from pathlib import Path

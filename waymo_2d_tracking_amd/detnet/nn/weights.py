@@ -12,7 +12,6 @@ detectron2's (c, ph, pw) flatten order to the NHWC (ph, pw, c) order.
 test-suite checks it entry by entry against the module tree the reference printed (tests/golden/x152_modules.json, from
 logs/12442/job.log:336-1221) - the structural pin of a detector whose arithmetic cannot be pinned (detectron2 is absent).
 """
-import math
 
 import torch
 
