@@ -109,6 +109,12 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
                           const float* scale, const float* bias, int relu,
                           int batch, int h, int w, int c_in, int c_out, int groups, int stride, int pad,
                           float* y, void* stream);
+/* Same, with a per-layer hint: far_offsets != 0 marks a layer whose learned offsets move many samples further than the 2-pixel halo
+ * of the persistent kernel's input patch (calibrated once per layer by the caller, detnet/nn/cascade_rcnn.py); such layers take the
+ * per-tile fallback kernel (offset spread 2 px: 144 vs 171 us on res4). */
+int wd_deform_conv3x3_hint_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
+                               const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
+                               int c_out, int groups, int stride, int pad, int far_offsets, float* y, void* stream);
 
 /* Box-head FC / 1x1 convolution as GEMM on f32-input MFMA:  C = act(A (M,K) * B^T + bias [+ residual])
  *   A row-major (M,K) float32; Bt row-major (N,K) float32 (a torch Linear / 1x1-conv weight as stored);

@@ -786,6 +786,13 @@ int wd_deform_pack_weight(const float* weight_oihw, int c_in, int c_out, int gro
 int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
                           const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
                           int c_out, int groups, int stride, int pad, float* y, void* stream_) {
+    return wd_deform_conv3x3_hint_f32(x, offset, mask, packed_weight, scale, bias, relu, batch, h, w, c_in, c_out, groups, stride, pad,
+                                      0, y, stream_);
+}
+
+int wd_deform_conv3x3_hint_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
+                               const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
+                               int c_out, int groups, int stride, int pad, int far_offsets, float* y, void* stream_) {
     WT_TRY(wt::ensure_device());
     if (c_in != c_out || groups <= 0 || c_in % groups || c_in % CCH || stride < 1 || batch < 1 || h < 1 || w < 1 ||
         ((uintptr_t)x & 15)) {
@@ -814,7 +821,8 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
     // convolution and 8 channels per group -> L1-gather kernel.  WD_DEFORM_PATCH=lds|all|none overrides (experiments).
     const char* mode = getenv("WD_DEFORM_PATCH");
     int variant = deform_variant(cg, stride, pad, offset != nullptr, mode);
-    if (variant == 3 && mask) variant = 2;                   // the ping-pong kernel has no modulation mask
+    if (variant == 3 && (mask || far_offsets)) variant = 2;  // the ping-pong kernel has no modulation mask; with many samples leaving
+                                                             // the 14x14 patch its per-lane far path loses to the per-tile one
     if (variant == 3)
         return wd_deform_pp_launch(x, offset, packed_weight, scale, bias, relu, batch, h, w, c_in, stream, y);
     if (variant == 2) {

@@ -128,7 +128,7 @@ def deform_pack_weight(weight, groups):
     return packed
 
 
-def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None, bias=None, relu=False, mask=None):
+def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None, bias=None, relu=False, mask=None, far_offsets=False):
     """detectron2 DeformConv (3x3, dilation 1, deformable_groups 1) + fused FrozenBN affine / ReLU.
     x (N,C,H,W), offset (N,18,Ho,Wo), optional mask (N,9,Ho,Wo); returns (N,C,Ho,Wo) channels_last."""
     x = _nhwc(x)
@@ -146,18 +146,31 @@ def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().wd_deform_conv3x3_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
-                                                C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
-                                                C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad), _p(y), _stream()),
-               'wd_deform_conv3x3_f32')
+    _lib.check(_lib.lib().wd_deform_conv3x3_hint_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
+                                                     C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+                                                     C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad),
+                                                     C.c_int(1 if far_offsets else 0), _p(y), _stream()), 'wd_deform_conv3x3_f32')
     if log is not None:
         e1.record()
         fn = _lib.lib().wd_deform_conv3x3_variant
         fn.restype = C.c_char_p
         name = fn(C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad), C.c_int(0 if offset is None else 1)).decode()
+        if far_offsets and 'pp_kernel' in name:
+            name = 'deform_conv3x3_lds_kernel<32>'
         log.append(('%s: deform_conv3x3 C=%d %dx%d s%d%s' % (name, c, ho, wo, stride, '' if offset is not None else ' (no offsets)'),
                     2.0 * c * (c // groups) * 9 * ho * wo * n, e0, e1))
     return y
+
+
+FAR_OFFSET_PX = 2.0          # halo of the persistent kernel's 14x14 input patch
+FAR_OFFSET_SHARE = 0.2       # share of samples beyond it from which the per-tile fallback kernel wins
+
+
+def far_offset_share(offset):
+    """Share of (pixel, tap) samples whose learned offset exceeds the persistent deform kernel's halo in y or x.
+    Synchronises (one number to the host): call once per layer, outside stream capture."""
+    n, _, h, w = offset.shape
+    return float((offset.abs() > FAR_OFFSET_PX).reshape(n, 9, 2, h, w).any(dim=2).float().mean().item())
 
 
 def gemm_nt(a, bt, bias=None, residual=None, relu=False, out=None):
