@@ -32,6 +32,7 @@ UNITS = {
     'det_nms.hip': [],
     'det_deform.hip': [],
     'det_deform_pp.hip': [],
+    'det_gconv.hip': [],
     'det_gemm.hip': ['-munsafe-fp-atomics'],
     'det_gemm_lt.hip': [],
     'det_misc.hip': [],

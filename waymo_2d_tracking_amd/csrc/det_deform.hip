@@ -740,6 +740,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout
 
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
                         const float* bias, int relu, int batch, int h, int w, int c, hipStream_t stream, float* y);
+int wd_grouped_conv3x3_c8_launch(const float* x, const float* packed_weight, const float* scale, const float* bias, int relu,
+                                 int batch, int h, int w, int c, hipStream_t stream, float* y);
 
 // 0 = L1-gather kernel, 1 = LDS patch + shared slab, 2 = LDS patch + register A fragments, 3 = ping-pong (det_deform_pp.hip)
 static int deform_variant(int cg, int stride, int pad, bool has_offset, const char* mode) {
@@ -763,6 +765,7 @@ const char* wd_deform_conv3x3_variant(int c_in, int groups, int stride, int pad,
         case 1: return cg == 16 ? "deform_conv3x3_patch_kernel<16>" : cg == 32 ? "deform_conv3x3_patch_kernel<32>" : "deform_conv3x3_patch_kernel<64>";
         default: break;
     }
+    if (!has_offset && cg == 8 && stride == 1 && pad == 1 && (c_in % 128) == 0) return "grouped_conv3x3_c8_kernel";
     if (has_offset) return cg == 8 ? "deform_conv3x3_kernel<8,true>" : cg == 16 ? "deform_conv3x3_kernel<16,true>" : cg == 32 ? "deform_conv3x3_kernel<32,true>" : "deform_conv3x3_kernel<64,true>";
     return cg == 8 ? "deform_conv3x3_kernel<8,false>" : cg == 16 ? "deform_conv3x3_kernel<16,false>" : cg == 32 ? "deform_conv3x3_kernel<32,false>" : "deform_conv3x3_kernel<64,false>";
 }
@@ -820,6 +823,12 @@ int wd_deform_conv3x3_hint_f32(const float* x, const float* offset, const float*
     // (16 / 32 channels per group: register-fragment kernel, 64: shared-slab patch kernel); stride 2, plain grouped
     // convolution and 8 channels per group -> L1-gather kernel.  WD_DEFORM_PATCH=lds|all|none overrides (experiments).
     const char* mode = getenv("WD_DEFORM_PATCH");
+    // res2: plain grouped conv with 8 channels per group -> vector-unit kernel (det_gconv.hip); WD_GCONV=mfma keeps the MFMA path
+    if (!offset && !mask && cg == 8 && stride == 1 && pad == 1 && (c_in % 128) == 0 && ((uintptr_t)y & 7) == 0) {
+        const char* gm = getenv("WD_GCONV");
+        if (!(gm && strcmp(gm, "mfma") == 0))
+            return wd_grouped_conv3x3_c8_launch(x, packed_weight, scale, bias, relu, batch, h, w, c_in, stream, y);
+    }
     int variant = deform_variant(cg, stride, pad, offset != nullptr, mode);
     if (variant == 3 && (mask || far_offsets)) variant = 2;  // the ping-pong kernel has no modulation mask; with many samples leaving
                                                              // the 14x14 patch its per-lane far path loses to the per-tile one
