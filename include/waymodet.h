@@ -59,6 +59,11 @@ int wd_gemm_nt_ws_f32(const float* A, const float* Bt, const float* bias, const 
 int wd_gemm_lt_f32(const float* a, const float* w, const float* bias, const float* residual, float* out, int m, int n, int k,
                    int relu, void* workspace, size_t workspace_bytes, void* stream);
 int wd_gemm_lt_plan_info(int m, int n, int k, int relu, int has_bias, int has_residual, float* best_us, int* candidates);
+/* wd_nms_sorted_f32 on n_seg (<= 8) independent row ranges in one pair of launches: detectron2's per-level batched_nms of the RPN
+ * (find_top_rpn_proposals) with the levels' suppression chains in parallel workgroups.  Every range is sorted by descending
+ * score; idxs may still mark rows that must not suppress (group -1).  n_keep: n_seg device ints. */
+int wd_nms_segmented_f32(const float* boxes, const int32_t* idxs, const int32_t* seg_offsets, int n_seg, float iou_threshold,
+                         uint8_t* keep_mask, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
 
 /* --- fused, static-shape tail of the detector (csrc/det_tail.hip): one launch per step, no host round trip ------------
  * RPN.predict_proposals (detectron2 proposal_utils.find_top_rpn_proposals, called from detectron2_det/__init__.py:74 via the
@@ -72,8 +77,8 @@ int wd_rpn_topk_decode_f32(const float* const* logits, const float* const* delta
                            size_t workspace_bytes, void* stream);
 /* Stable descending score sort of n <= 8192 candidate rows, gathered into sorted order (the `scores.sort(descending=True)` in
  * front of batched_nms); out_order[t] = source row of sorted row t. */
-int wd_sort_candidates_f32(const float* boxes, const float* scores, const int32_t* group, const uint8_t* valid, int n,
-                           float* out_boxes, float* out_scores, int32_t* out_group, uint8_t* out_valid, int64_t* out_order,
+int wd_sort_candidates_f32(const float* boxes, const float* scores, const int32_t* group, const uint8_t* valid,
+                           const uint8_t* valid2 /* nullable: ANDed into valid (e.g. a keep mask) */, int n, float* out_boxes, float* out_scores, int32_t* out_group, uint8_t* out_valid, int64_t* out_order,
                            void* stream);
 /* fast_rcnn_inference_single_image candidates: every (row, class) pair of the last cascade stage, score = (s0 + s1 + s2) / 3 of
  * the three stages' softmax (rows x (classes + 1)); a pair is real when its row < *n_valid, box and scores are finite and the

@@ -152,3 +152,34 @@ def test_gemm_lt_residual_bias_relu(m, n, k):
                                rtol=2e-4, atol=2e-4)
     got3 = ops.gemm_lt(a, w, None, None, False)
     np.testing.assert_allclose(got3.cpu().double().numpy(), (a.double() @ w.double().t()).cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('sizes', [(1000, 1000, 1000, 1000, 1000), (1000, 37, 1, 640), (64,), (1000, 0, 500)])
+def test_segmented_nms_equals_grouped_nms_on_the_globally_sorted_list(sizes):
+    """wd_nms_segmented_f32 (one sweep chain per FPN level, in parallel) keeps exactly the boxes that the single-chain NMS with
+    group ids keeps, and the RPN selection built on it (sort with valid = kept, first `post`) equals sort -> NMS -> first `post`."""
+    g = torch.Generator().manual_seed(sum(sizes) + len(sizes))
+    boxes_l, scores_l, lvl_l = [], [], []
+    for l, n in enumerate(sizes):
+        b = _boxes(g, n, 600.0)
+        if n > 3:
+            b[1::3] = b[0:-1:3][:b[1::3].shape[0]] + 2.0              # overlapping clusters -> suppression chains
+        s = torch.sort(torch.round(torch.randn(n, generator=g) * 16) / 16, descending=True).values.cuda()    # sorted, with ties
+        boxes_l.append(b); scores_l.append(s); lvl_l.append(torch.full((n,), l, dtype=torch.int32, device='cuda'))
+    boxes, scores, lvls = torch.cat(boxes_l), torch.cat(scores_l), torch.cat(lvl_l)
+    n = boxes.shape[0]
+    ok = (torch.rand(n, generator=g) < 0.95).to(torch.uint8).cuda()
+    lvls = torch.where(ok.bool(), lvls, torch.full_like(lvls, -1))      # "empty" boxes neither suppress nor get selected
+    seg = [0]
+    for m in sizes:
+        seg.append(seg[-1] + m)
+    keep = ops.nms_segmented(boxes, lvls, seg, 0.7)
+    sb, ss, sg, sv, order = ops.sort_candidates(boxes, scores, lvls, ok, keep)
+    got, got_n = ops.gather_kept(sv, sv, sb, ss, order, 300)
+    # reference order of operations: global stable sort, one NMS chain with group ids, first 300 kept & valid
+    rb, rs, rg, rv, rorder = ops.sort_candidates(boxes, scores, lvls, ok)
+    rkeep = ops.nms_sorted_mask(rb, rg, 0.7)
+    want, want_n = ops.gather_kept(rkeep, rv, rb, rs, rorder, 300)
+    real = rv.bool()                                                  # rows flagged empty share group -1: what they do to each other is irrelevant
+    assert torch.equal(keep[rorder][real], rkeep[real])
+    assert int(got_n.item()) == int(want_n.item()) and torch.equal(got, want)

@@ -22,11 +22,31 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
     return (inter / (sa + sb - inter)) > thr;
 }
 
+// Independent problems in one launch (segments = FPN levels of the RPN candidates): problem z = rows [off[z], off[z + 1]),
+// blockIdx.z (mask) / blockIdx.x (sweep) selects it; n_seg == 0: one problem over all n rows.
+struct NmsSegs { int n_seg; int off[9]; };
+
+__device__ __forceinline__ size_t seg_mask_words(const NmsSegs& sg, int z) {      // mask words in front of problem z
+    size_t w = 0;
+    for (int q = 0; q < z; ++q) { const size_t m = (size_t)(sg.off[q + 1] - sg.off[q]); w += m * ((m + 63) / 64); }
+    return w;
+}
+
 template <bool COLMAJOR>     // COLMAJOR: mask[column tile][row] (the column sweep reads a tile's words of consecutive rows coalesced)
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes, const int32_t* __restrict__ idxs,
                                                       int n, int nb, float thr, unsigned long long* __restrict__ mask,
-                                                      unsigned long long* __restrict__ diag_pred) {
+                                                      unsigned long long* __restrict__ diag_pred, NmsSegs sg) {
     const int bi = blockIdx.y, bj = blockIdx.x;
+    if (sg.n_seg) {
+        const int z = blockIdx.z, base = sg.off[z];
+        n = sg.off[z + 1] - base;
+        nb = (n + 63) / 64;
+        if (bi >= nb || bj >= nb) return;
+        boxes += base;
+        if (idxs) idxs += base;
+        diag_pred += base;
+        mask += seg_mask_words(sg, z);
+    }
     if (bj < bi) return;
     __shared__ float4 cb[64];
     __shared__ int cg[64];
@@ -125,7 +145,16 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long
 template <int MAXR>
 __global__ __launch_bounds__(256) void nms_sweep_col_kernel(const unsigned long long* __restrict__ maskT,
                                                             const unsigned long long* __restrict__ diag_pred, int n, int nb,
-                                                            uint8_t* __restrict__ keep, int32_t* __restrict__ n_keep) {
+                                                            uint8_t* __restrict__ keep, int32_t* __restrict__ n_keep, NmsSegs sg) {
+    if (sg.n_seg) {
+        const int z = blockIdx.x, base = sg.off[z];
+        n = sg.off[z + 1] - base;
+        nb = (n + 63) / 64;
+        maskT += seg_mask_words(sg, z);
+        diag_pred += base;
+        keep += base;
+        n_keep += z;
+    }
     extern __shared__ unsigned long long sh[];             // keptw[nb] + red
     unsigned long long* keptw = sh;
     unsigned long long* red = sh + nb;
@@ -254,14 +283,57 @@ int wd_nms_sorted_f32(const float* boxes, const int32_t* idxs, int n, float iou_
     const char* mode = getenv("WD_NMS_SWEEP");              // experiments: "row" forces the row sweep
     if (n <= 256 * kMaxR && !(mode && strcmp(mode, "row") == 0)) {
         hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(nb, nb), dim3(64), 0, stream, (const float4*)boxes, idxs, n, nb,
-                           iou_threshold, mask, diag_pred);
+                           iou_threshold, mask, diag_pred, NmsSegs{});
         hipLaunchKernelGGL(nms_sweep_col_kernel<kMaxR>, dim3(1), dim3(256), (size_t)(nb + 1) * 8, stream, mask, diag_pred, n, nb,
-                           keep_mask, n_keep);
+                           keep_mask, n_keep, NmsSegs{});
     } else {
         hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(nb, nb), dim3(64), 0, stream, (const float4*)boxes, idxs, n, nb,
-                           iou_threshold, mask, diag_pred);
+                           iou_threshold, mask, diag_pred, NmsSegs{});
         hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), (size_t)(nb + 1) * 8, stream, mask, n, nb, removed, keep_mask,
                            n_keep);
+    }
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+/* The same NMS on n_seg independent row ranges [seg_offsets[z], seg_offsets[z + 1]) in ONE pair of launches (RPN: one range per
+ * FPN level, each sorted by descending score): the suppression chains of the ranges run in parallel workgroups instead of one
+ * 75-tile chain.  seg_offsets: host array of n_seg + 1 ints; n_keep: n_seg device ints; workspace as for n rows. */
+int wd_nms_segmented_f32(const float* boxes, const int32_t* idxs, const int32_t* seg_offsets, int n_seg, float iou_threshold,
+                         uint8_t* keep_mask, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream_) {
+    WT_TRY(wt::ensure_device());
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_seg < 1 || n_seg > 8 || !seg_offsets || !boxes || !keep_mask || !n_keep || ((uintptr_t)boxes & 15)) {
+        wt::set_error("wd_nms_segmented_f32: bad argument (1..8 segments)");
+        return WT_ERR_INVALID;
+    }
+    constexpr int kMaxR = 24;
+    NmsSegs sg{};
+    sg.n_seg = n_seg;
+    int max_n = 0;
+    for (int z = 0; z <= n_seg; ++z) sg.off[z] = seg_offsets[z];
+    for (int z = 0; z < n_seg; ++z) {
+        const int m = sg.off[z + 1] - sg.off[z];
+        if (m < 0 || m > 256 * kMaxR) { wt::set_error("wd_nms_segmented_f32: segment %d has %d rows (0..%d)", z, m, 256 * kMaxR); return WT_ERR_INVALID; }
+        max_n = m > max_n ? m : max_n;
+    }
+    const int n = sg.off[n_seg] - sg.off[0];
+    if (n <= 0) { WT_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t) * n_seg, stream)); return WT_OK; }
+    if (sg.off[0] != 0 || !workspace || workspace_bytes < wd_nms_workspace(n)) {
+        wt::set_error("wd_nms_segmented_f32: offsets must start at 0 / workspace too small");
+        return WT_ERR_CAPACITY;
+    }
+    const int nbm = (max_n + 63) / 64;
+    const uintptr_t mis = (uintptr_t)workspace & 255;
+    wt::Carver cv((char*)workspace + (mis ? 256 - mis : 0));
+    unsigned long long* mask = cv.take<unsigned long long>((size_t)n * ((n + 63) / 64));
+    (void)cv.take<unsigned long long>((size_t)((n + 63) / 64) + 1);
+    unsigned long long* diag_pred = cv.take<unsigned long long>((size_t)n);
+    if (nbm > 0) {
+        hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(nbm, nbm, n_seg), dim3(64), 0, stream, (const float4*)boxes, idxs, n, nbm,
+                           iou_threshold, mask, diag_pred, sg);
+        hipLaunchKernelGGL(nms_sweep_col_kernel<kMaxR>, dim3(n_seg), dim3(256), (size_t)(nbm + 1) * 8, stream, mask, diag_pred, n, nbm,
+                           keep_mask, n_keep, sg);
     }
     WT_HIP(hipGetLastError());
     return WT_OK;

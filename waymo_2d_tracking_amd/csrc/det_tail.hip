@@ -122,6 +122,7 @@ __global__ __launch_bounds__(kThreads) void rpn_topk_stage_kernel(TopkStage st, 
 // Candidate sources of sort_candidates_kernel.
 struct CandRpn {                       // rows already hold boxes / scores / groups / valid flags
     const float4* boxes; const float* scores; const int* group; const unsigned char* valid;
+    const unsigned char* valid2;       // optional second flag (the per-level NMS keep mask), ANDed into valid
 };
 struct CandBox {                       // (row, class) pairs of the last cascade stage
     const float4* boxes;               // (r, 4) unclipped
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void sort_candidates_kernel(CandRpn a, Ca
         if (MODE == 0) {
             out_boxes[t] = a.boxes[i];
             out_group[t] = a.group[i];
-            out_valid[t] = a.valid[i];
+            out_valid[t] = a.valid[i] & (a.valid2 ? a.valid2[i] : (unsigned char)1);
         } else {
             const int row = i / c.nc, cls = i - row * c.nc;
             float4 b = c.boxes[row];
@@ -336,15 +337,15 @@ int wd_rpn_topk_decode_f32(const float* const* logits, const float* const* delta
 }
 
 // Stable descending sort of RPN candidates (n <= 8192) and gather into sorted order.
-int wd_sort_candidates_f32(const float* boxes, const float* scores, const int32_t* group, const uint8_t* valid, int n,
-                           float* out_boxes, float* out_scores, int32_t* out_group, uint8_t* out_valid, int64_t* out_order,
+int wd_sort_candidates_f32(const float* boxes, const float* scores, const int32_t* group, const uint8_t* valid,
+                           const uint8_t* valid2, int n, float* out_boxes, float* out_scores, int32_t* out_group, uint8_t* out_valid, int64_t* out_order,
                            void* stream) {
     WT_TRY(wt::ensure_device());
     if (n < 1 || n > kChunk || !boxes || !scores || !group || !valid) {
         wt::set_error("wd_sort_candidates_f32: bad argument (n=%d, at most %d)", n, kChunk);
         return WT_ERR_INVALID;
     }
-    CandRpn a{(const float4*)boxes, scores, group, valid};
+    CandRpn a{(const float4*)boxes, scores, group, valid, valid2};
     CandBox c{};
     hipLaunchKernelGGL(sort_candidates_kernel<0>, dim3(1), dim3(kThreads), (size_t)kChunk * 8, (hipStream_t)stream, a, c, n,
                        (float4*)out_boxes, out_scores, out_group, out_valid, (long long*)out_order);

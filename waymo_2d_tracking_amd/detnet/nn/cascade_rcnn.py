@@ -294,9 +294,15 @@ class RPN(nn.Module):
         # shapes, no host round trip: an empty box keeps its slot but can neither suppress (group -1) nor be selected (valid
         # 0); the result is always (post, 4) - unused rows are zero boxes - plus the device-side count of real proposals
         boxes, scores, lvls, ok = ops.rpn_topk_decode(logits_l, deltas_l, anchors_l, self.pre, img_h, img_w)
-        sb, ss, sg, sv, order = ops.sort_candidates(boxes, scores, lvls, ok)
-        keep = ops.nms_sorted_mask(sb, sg, self.thr)
-        props, count = ops.gather_kept(keep, sv, sb, ss, order, self.post)
+        # per-level NMS on the per-level sorted lists (the levels' suppression chains run in parallel workgroups), THEN the
+        # global stable score sort with valid = non-empty & kept, and the first `post` of those: the same proposals as sorting
+        # first and sweeping one 5000-box chain (batched_nms never lets levels interact)
+        seg = [0]
+        for lg in logits_l:
+            seg.append(seg[-1] + min(self.pre, lg.numel()))
+        keep = ops.nms_segmented(boxes, lvls, seg, self.thr)
+        sb, ss, sg, sv, order = ops.sort_candidates(boxes, scores, lvls, ok, keep)
+        props, count = ops.gather_kept(sv, sv, sb, ss, order, self.post)
         return props, count
 
 

@@ -298,13 +298,35 @@ def _sorted_outputs(n, dev):
             torch.empty(n, dtype=torch.int64, device=dev))
 
 
-def sort_candidates(boxes, scores, group, valid):
-    """Stable descending score sort of <= 8192 candidate rows + gather: (boxes, scores, group, valid, order) sorted."""
+def sort_candidates(boxes, scores, group, valid, valid2=None):
+    """Stable descending score sort of <= 8192 candidate rows + gather: (boxes, scores, group, valid [& valid2], order) sorted."""
     n = boxes.shape[0]
     out = _sorted_outputs(n, boxes.device)
-    _lib.check(_lib.lib().wd_sort_candidates_f32(_p(boxes), _p(scores), _p(group), _p(valid), C.c_int(n), *[_p(t) for t in out],
-                                                 _stream()), 'wd_sort_candidates_f32')
+    _lib.check(_lib.lib().wd_sort_candidates_f32(_p(boxes), _p(scores), _p(group), _p(valid), _p(valid2), C.c_int(n),
+                                                 *[_p(t) for t in out], _stream()), 'wd_sort_candidates_f32')
     return out
+
+
+def nms_segmented(boxes, idxs, seg_offsets, iou_threshold):
+    """Greedy NMS on independent row ranges (each sorted by descending score) in one pair of launches -> uint8 keep mask.
+    seg_offsets: python list of n_seg + 1 row offsets starting at 0."""
+    n = boxes.shape[0]
+    keep = torch.zeros(n, dtype=torch.uint8, device=boxes.device)
+    if n == 0:
+        return keep
+    lib = _lib.lib()
+    need = int(lib.wd_nms_workspace(C.c_int(n)))
+    key = (boxes.device, torch.cuda.current_stream().cuda_stream)
+    ws = _nms_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=boxes.device)
+        _nms_ws[key] = ws
+    n_seg = len(seg_offsets) - 1
+    cnt = torch.zeros(n_seg, dtype=torch.int32, device=boxes.device)
+    offs = (C.c_int32 * (n_seg + 1))(*[int(v) for v in seg_offsets])
+    _lib.check(lib.wd_nms_segmented_f32(_p(boxes.contiguous()), _p(idxs), offs, C.c_int(n_seg), C.c_float(iou_threshold), _p(keep),
+                                        _p(cnt), _p(ws), C.c_size_t(ws.numel()), _stream()), 'wd_nms_segmented_f32')
+    return keep
 
 
 def box_candidates(boxes, s0, s1, s2, n_valid, score_thresh, img_h, img_w):
