@@ -47,7 +47,11 @@ constexpr size_t SMEM = (size_t)BW_F * 4 + 4 * (size_t)PATCH_F * 4 + 2 * (size_t
 // Workgroup barrier without the fence of __syncthreads(): the fence makes every wave wait for its outstanding LDS READS
 // (lgkmcnt(0)), which need no ordering; the LDS writes that do (table rewrite, zero fill of edge patches, patch DMA) are
 // followed by explicit waits.
+#ifdef PP_NO_BARRIER      // experiments: upper bound of what the two workgroup barriers per tile cost (results are wrong)
+#define PP_BARRIER() do { asm volatile("" ::: "memory"); } while (0)
+#else
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
 #ifndef PP_DMA_K
 #define PP_DMA_K 5
 #endif
