@@ -120,6 +120,17 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
 int wd_deform_conv3x3_hint_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
                                const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
                                int c_out, int groups, int stride, int pad, int far_offsets, float* y, void* stream);
+/* The persistent kernel's sampling table (one entry per pixel and tap: 4 corner slots + bilinear fractions) depends on the offsets
+ * only, not on the channel group: wd_deform_offsets_table_f32 builds it once per layer inside the offset conv's epilogue launch
+ * (it replaces wd_tap_shift_add_f32 there: same offsets, same arithmetic), wd_deform_conv3x3_tab_f32 consumes it (table may be
+ * NULL = the kernel builds its own entries; ignored by the other kernel variants).  Same batch / h / w on both calls. */
+size_t wd_deform_table_bytes(int batch, int h, int w);
+int wd_deform_offsets_table_f32(const float* partial, int ld, const float* bias, int batch, int h, int w, float* offsets,
+                                void* table, void* stream);
+int wd_deform_conv3x3_tab_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
+                              const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
+                              int c_out, int groups, int stride, int pad, int far_offsets, const void* table, float* y,
+                              void* stream);
 
 /* Box-head FC / 1x1 convolution as GEMM on f32-input MFMA:  C = act(A (M,K) * B^T + bias [+ residual])
  *   A row-major (M,K) float32; Bt row-major (N,K) float32 (a torch Linear / 1x1-conv weight as stored);

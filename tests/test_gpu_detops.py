@@ -387,3 +387,23 @@ def test_deform_far_offset_hint_selects_the_fallback_kernel_with_equal_results()
     finally:
         O.EVENT_LOG = None
     assert names == ['deform_conv3x3_lds_kernel<32>', 'deform_conv3x3_pp_kernel<32>'], names
+
+
+@pytest.mark.parametrize('H,W,batch,off_std', [(80, 120, 1, 0.7), (19, 23, 2, 2.5), (8, 8, 1, 0.0)])
+def test_deform_table_prepass_equals_in_kernel_table(H, W, batch, off_std):
+    """wd_deform_offsets_table_f32 (offset conv gather + sampling table in one launch) gives the offsets of wd_tap_shift_add_f32
+    bit for bit, and the persistent kernel fed with that table the output it computes with its own in-kernel table."""
+    from waymo_2d_tracking_amd.detnet.nn import ops as O
+    g = torch.Generator().manual_seed(H * W + batch)
+    C = 1024
+    x = torch.randn((batch, C, H, W), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    packed = O.deform_pack_weight((torch.randn((C, 32, 3, 3), generator=g) * 0.05).cuda(), 32)
+    w_off = (torch.randn((18, C, 3, 3), generator=g) * (off_std / 96.0)).cuda()
+    b_off = (torch.randn(18, generator=g) * 0.1 * off_std).cuda()
+    w2 = O.tap_gemm_weight(w_off)
+    off_a = O.conv3x3_few(x, w2, b_off, 18, 1)
+    off_b, table = O.conv3x3_few(x, w2, b_off, 18, 1, deform_table=True)
+    assert torch.equal(off_a, off_b)
+    ya = O.deform_conv3x3(x, off_a, packed, 32, 1, 1)
+    yb = O.deform_conv3x3(x, off_b, packed, 32, 1, 1, table=table)
+    assert torch.equal(ya, yb)

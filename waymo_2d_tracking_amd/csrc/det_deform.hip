@@ -739,7 +739,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout
 }  // namespace
 
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
-                        const float* bias, int relu, int batch, int h, int w, int c, hipStream_t stream, float* y);
+                        const float* bias, int relu, int batch, int h, int w, int c, hipStream_t stream, float* y, const void* table);
 int wd_grouped_conv3x3_c8_launch(const float* x, const float* packed_weight, const float* scale, const float* bias, int relu,
                                  int batch, int h, int w, int c, hipStream_t stream, float* y);
 
@@ -789,13 +789,21 @@ int wd_deform_pack_weight(const float* weight_oihw, int c_in, int c_out, int gro
 int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
                           const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
                           int c_out, int groups, int stride, int pad, float* y, void* stream_) {
-    return wd_deform_conv3x3_hint_f32(x, offset, mask, packed_weight, scale, bias, relu, batch, h, w, c_in, c_out, groups, stride, pad,
-                                      0, y, stream_);
+    return wd_deform_conv3x3_tab_f32(x, offset, mask, packed_weight, scale, bias, relu, batch, h, w, c_in, c_out, groups, stride, pad,
+                                     0, nullptr, y, stream_);
 }
 
 int wd_deform_conv3x3_hint_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
                                const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
                                int c_out, int groups, int stride, int pad, int far_offsets, float* y, void* stream_) {
+    return wd_deform_conv3x3_tab_f32(x, offset, mask, packed_weight, scale, bias, relu, batch, h, w, c_in, c_out, groups, stride, pad,
+                                     far_offsets, nullptr, y, stream_);
+}
+
+int wd_deform_conv3x3_tab_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
+                              const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
+                              int c_out, int groups, int stride, int pad, int far_offsets, const void* table, float* y,
+                              void* stream_) {
     WT_TRY(wt::ensure_device());
     if (c_in != c_out || groups <= 0 || c_in % groups || c_in % CCH || stride < 1 || batch < 1 || h < 1 || w < 1 ||
         ((uintptr_t)x & 15)) {
@@ -833,7 +841,7 @@ int wd_deform_conv3x3_hint_f32(const float* x, const float* offset, const float*
     if (variant == 3 && (mask || far_offsets)) variant = 2;  // the ping-pong kernel has no modulation mask; with many samples leaving
                                                              // the 14x14 patch its per-lane far path loses to the per-tile one
     if (variant == 3)
-        return wd_deform_pp_launch(x, offset, packed_weight, scale, bias, relu, batch, h, w, c_in, stream, y);
+        return wd_deform_pp_launch(x, offset, packed_weight, scale, bias, relu, batch, h, w, c_in, stream, y, table);
     if (variant == 2) {
         const long nwg_p = ntiles * (c_in / PCH);
         dim3 gridp((unsigned)((nwg_p + 7) / 8 * 8));

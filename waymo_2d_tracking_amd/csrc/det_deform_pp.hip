@@ -85,10 +85,81 @@ __device__ __forceinline__ int pp_tab_slot(int e) { return e; }      // measured
 // 16-byte slot index of quad q (0..7) of patch pixel p
 __device__ __forceinline__ int pp_slot(int p, int q) { return (p << 3) + (q ^ ((p >> 1) & 7)); }
 
+// Sampling-table entry of (pixel, tap): the four corner slots (byte offsets inside a patch buffer) + the bilinear fractions.
+// t_fy / t_fx = undeformed sample position in patch coordinates (pixel row + kh + 2, pixel column + kw + 2); (ty, tx) = tile.  One
+// function for the in-kernel table build and for the per-layer pre-pass (deform_offsets_table_kernel): identical entries.
+__device__ __forceinline__ uint4 pp_make_entry(bool pixel_in_image, float t_fy, float t_fx, float2 ov, int ty, int tx, int H, int W) {
+    const float py0 = (float)(ty * 8 - 3), px0 = (float)(tx * 8 - 3);
+    const float fH = (float)H, fW = (float)W;
+    unsigned s0 = pp_slot(pp::NPIX, 0), s1 = s0, s2 = s0, s3 = s0;        // the zero pixel: contributes nothing
+    float lh = 0.f, lw = 0.f;
+    if (pixel_in_image) {
+        const float ry = t_fy + ov.x, rx = t_fx + ov.y;                   // patch coordinates
+        const float h_im = ry + py0, w_im = rx + px0;
+        if (h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW) {
+            const float fy = floorf(ry), fx = floorf(rx);
+            const int hl = (int)fy, wl = (int)fx;
+            if ((unsigned)hl <= (unsigned)(pp::PS - 2) && (unsigned)wl <= (unsigned)(pp::PS - 2)) {
+                const int u = hl * pp::PS + wl;
+                lh = ry - fy; lw = rx - fx;
+                s0 = pp_slot(u, 0); s1 = pp_slot(u + 1, 0); s2 = pp_slot(u + pp::PS, 0); s3 = pp_slot(u + pp::PS + 1, 0);
+            } else {
+                lh = pp::FAR;                                             // the lane recomputes this sample from global memory
+            }
+        }
+    }
+    uint4 e;
+    e.x = (s0 << 4) | (s1 << 20); e.y = (s2 << 4) | (s3 << 20);           // byte offsets inside the patch buffer (< 2^16)
+    e.z = __float_as_uint(lh); e.w = __float_as_uint(lw);
+    return e;
+}
+
+// Per-layer pre-pass, fused with the offset conv's tap gather (det_misc.hip tap_shift_add_kernel, same arithmetic and order):
+// thread = (tile, pixel, tap).  Writes the two offsets of the tap (NHWC, 18 per pixel) and the table entry the persistent kernel
+// would otherwise rebuild in EVERY one of its 32 channel-group workgroups (7 us of 93 on res4).  table[tile][pixel * 9 + tap],
+// tile = (n * tiles_y + ty) * tiles_x + tx; slots of pixels outside the image hold the zero-pixel entry.
+__global__ __launch_bounds__(256) void deform_offsets_table_kernel(const float* __restrict__ partial, int ld,
+                                                                  const float* __restrict__ bias, int batch, int H, int W,
+                                                                  float* __restrict__ offsets, uint4* __restrict__ table) {
+    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const long total = (long)batch * tiles_y * tiles_x * pp::NE;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int e = (int)(i % pp::NE);
+        long tile = i / pp::NE;
+        const int tx = (int)(tile % tiles_x);
+        tile /= tiles_x;
+        const int ty = (int)(tile % tiles_y), tn = (int)(tile / tiles_y);
+        const int pxl = e / 9, k = e - 9 * pxl;
+        const int yy = pxl >> 3, xx = pxl & 7, kh = k / 3, kw = k - 3 * kh;
+        const int oy = ty * 8 + yy, ox = tx * 8 + xx;
+        const bool in = oy < H && ox < W;
+        float2 ov = make_float2(0.f, 0.f);
+        if (in) {
+            float a0 = bias ? bias[2 * k] : 0.f, a1 = bias ? bias[2 * k + 1] : 0.f;
+            const float* base = partial + (size_t)tn * H * W * ld + 2 * k;
+#pragma unroll
+            for (int qh = 0; qh < 3; ++qh) {
+                const int y = oy + qh - 1;
+                if (y < 0 || y >= H) continue;
+#pragma unroll
+                for (int qw = 0; qw < 3; ++qw) {
+                    const int x = ox + qw - 1;
+                    if (x < 0 || x >= W) continue;
+                    const float2 v = *reinterpret_cast<const float2*>(base + ((size_t)y * W + x) * ld + (qh * 3 + qw) * 18);
+                    a0 += v.x; a1 += v.y;
+                }
+            }
+            ov = make_float2(a0, a1);
+            *reinterpret_cast<float2*>(offsets + (((size_t)tn * H + oy) * W + ox) * 18 + 2 * k) = ov;
+        }
+        table[i] = pp_make_entry(in, (float)(yy + kh + 2), (float)(xx + kw + 2), ov, ty, tx, H, W);
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ wfrag,
     const float* __restrict__ scale, const float* __restrict__ bias, int relu,
-    int batch, int H, int W, int C, int Cout, int nsplit, float* __restrict__ y) {
+    int batch, int H, int W, int C, int Cout, int nsplit, float* __restrict__ y, const uint4* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bw = reinterpret_cast<float*>(smem);
     float* patch_all = bw + pp::BW_F;
@@ -158,7 +229,15 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
 
     // offsets of a tile (registers) and its patch (straight into LDS buffer `buf`)
     float2 ov[3];
+    uint4 tent[3];
     auto issue_offsets = [&](const TileXY& T) {
+        if (table) {                                            // per-layer pre-pass: this tile's entries, ready-made (3 loads per thread)
+            const uint4* tb = table + ((size_t)(T.tn * tiles_y + T.ty) * tiles_x + T.tx) * pp::NE;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (t_yx[j] != 0xFFFF) tent[j] = tb[tt + 256 * j];
+            return;
+        }
         const char* obase = ob + ((long)T.tn * HW + (long)(T.ty * 8) * W + T.tx * 8) * 72;
         const bool full = (T.ty * 8 + 8 <= H) && (T.tx * 8 + 8 <= W);
 #pragma unroll
@@ -212,30 +291,11 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     };
     // table entries of the next tile are computed into registers one per G slot (the table itself can only be rewritten in
     // G(7): entry 8 of the current tile is read in M(6), entry 0 of the next tile in M(7))
-    uint4 tent[3];
     auto compute_entry = [&](const TileXY& T, int j) {
-        const float py0 = (float)(T.ty * 8 - 3), px0 = (float)(T.tx * 8 - 3);
-        const float fH = (float)H, fW = (float)W;
+        if (table) return;                                      // entries of this tile were loaded by issue_offsets()
         const int yy = (t_yx[j] >> 8) & 255, xx = t_yx[j] & 255;
-        unsigned s0 = pp_slot(pp::NPIX, 0), s1 = s0, s2 = s0, s3 = s0;        // the zero pixel: contributes nothing
-        float lh = 0.f, lw = 0.f;
-        if (t_yx[j] != 0xFFFF && T.ty * 8 + yy < H && T.tx * 8 + xx < W) {
-            const float ry = t_fy[j] + ov[j].x, rx = t_fx[j] + ov[j].y;       // patch coordinates
-            const float h_im = ry + py0, w_im = rx + px0;
-            if (h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW) {
-                const float fy = floorf(ry), fx = floorf(rx);
-                const int hl = (int)fy, wl = (int)fx;
-                if ((unsigned)hl <= (unsigned)(pp::PS - 2) && (unsigned)wl <= (unsigned)(pp::PS - 2)) {
-                    const int u = hl * pp::PS + wl;
-                    lh = ry - fy; lw = rx - fx;
-                    s0 = pp_slot(u, 0); s1 = pp_slot(u + 1, 0); s2 = pp_slot(u + pp::PS, 0); s3 = pp_slot(u + pp::PS + 1, 0);
-                } else {
-                    lh = pp::FAR;                               // the lane recomputes this sample from global memory
-                }
-            }
-        }
-        tent[j].x = (s0 << 4) | (s1 << 20); tent[j].y = (s2 << 4) | (s3 << 20);        // byte offsets inside the patch buffer (< 2^16)
-        tent[j].z = __float_as_uint(lh); tent[j].w = __float_as_uint(lw);
+        const bool in = t_yx[j] != 0xFFFF && T.ty * 8 + yy < H && T.tx * 8 + xx < W;
+        tent[j] = pp_make_entry(in, t_fy[j], t_fx[j], ov[j], T.ty, T.tx, H, W);
     };
     auto write_table = [&]() {
 #pragma unroll
@@ -488,7 +548,7 @@ extern "C" int wd_debug_pp_prof(unsigned long long* out8, int reset) {
 
 // launcher used by wd_deform_conv3x3_f32 (det_deform.hip)
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
-                        const float* bias, int relu, int batch, int h, int w, int c, hipStream_t stream, float* y) {
+                        const float* bias, int relu, int batch, int h, int w, int c, hipStream_t stream, float* y, const void* table) {
     static bool attr_set = false;
     if (!attr_set) {
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel),
@@ -509,7 +569,31 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
     if (nsplit < 1) nsplit = 1;
     const float* wfrag = packed_weight + (size_t)c * pp::CG * 9;   // lane-major fragment copy (pack_weight_kernel)
     hipLaunchKernelGGL(deform_conv3x3_pp_kernel, dim3((unsigned)(groups * nsplit)), dim3(512), pp::SMEM, stream, x, offset,
-                       wfrag, scale, bias, relu, batch, h, w, c, c, nsplit, y);
+                       wfrag, scale, bias, relu, batch, h, w, c, c, nsplit, y, (const uint4*)table);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+extern "C" size_t wd_deform_table_bytes(int batch, int h, int w) {
+    return (size_t)batch * ((h + 7) / 8) * ((w + 7) / 8) * pp::NE * sizeof(uint4);
+}
+
+/* Offset conv epilogue + sampling table of the persistent deformable kernel in one launch: `partial` = the (pixels, ld >= 162) GEMM
+ * output of the 18-channel offset conv (ops.conv3x3_few), stride 1, pad 1.  offsets: (batch, h, w, 18) NHWC; table:
+ * wd_deform_table_bytes(batch, h, w) bytes, consumed by wd_deform_conv3x3_tab_f32 on the SAME (batch, h, w). */
+extern "C" int wd_deform_offsets_table_f32(const float* partial, int ld, const float* bias, int batch, int h, int w, float* offsets,
+                                           void* table, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (!partial || !offsets || !table || ld < 162 || (ld & 1) || batch < 1 || h < 1 || w < 1 || ((uintptr_t)partial & 7) ||
+        ((uintptr_t)offsets & 7) || ((uintptr_t)table & 15)) {
+        wt::set_error("wd_deform_offsets_table_f32: invalid arguments (ld=%d)", ld);
+        return WT_ERR_INVALID;
+    }
+    const long total = (long)batch * ((h + 7) / 8) * ((w + 7) / 8) * pp::NE;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(deform_offsets_table_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, ld, bias, batch,
+                       h, w, offsets, (uint4*)table);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

@@ -150,12 +150,12 @@ class Bottleneck(nn.Module):
             self._packed_v = v
         return self._packed
 
-    def offset_conv(self, x):
+    def offset_conv(self, x, deform_table=False):
         w = self.conv2_offset.weight
         if getattr(self, '_off_w2', None) is None or self._off_w2.device != w.device or self._off_v != w._version:
             self._off_w2 = ops.tap_gemm_weight(w)
             self._off_v = w._version
-        return ops.conv3x3_few(x, self._off_w2, self.conv2_offset.bias, 18, 1)
+        return ops.conv3x3_few(x, self._off_w2, self.conv2_offset.bias, 18, 1, deform_table)
 
     def forward(self, x):
         sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)
@@ -167,14 +167,20 @@ class Bottleneck(nn.Module):
         elif self.deform:
             # stride 1: library GEMM over the input pixels (162 columns) + tap shift-add kernel instead of a direct
             # 18-channel implicit GEMM (MIOpen pads N 18 -> 32 and adds the bias in a second pass)
-            offset = self.offset_conv(out) if self.stride == 1 else self.conv2_offset(out)
+            table = None
+            if self.stride == 1 and self.conv2_weight.shape[1] == 32:
+                # 32 channels per group (res4): the persistent kernel's sampling table is built once per layer inside the offset
+                # conv's gather launch instead of in each of the kernel's 32 channel-group workgroups
+                offset, table = self.offset_conv(out, deform_table=True)
+            else:
+                offset = self.offset_conv(out) if self.stride == 1 else self.conv2_offset(out)
             wv = self.conv2_offset.weight._version
             if self.stride == 1 and self._far_v != wv and not torch.cuda.is_current_stream_capturing():
                 # calibrated once per layer on the first frame it sees (one host sync, outside stream capture): layers whose
                 # learned offsets leave the persistent kernel's patch often take the per-tile fallback kernel
                 self._far_offsets, self._far_v = ops.far_offset_share(offset) > ops.FAR_OFFSET_SHARE, wv
             out = ops.deform_conv3x3(out, offset, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
-                                     self.conv2_bias, relu=True, far_offsets=bool(self._far_offsets))
+                                     self.conv2_bias, relu=True, far_offsets=bool(self._far_offsets), table=table)
         else:
             out = ops.deform_conv3x3(out, None, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
                                      self.conv2_bias, relu=True)

@@ -128,7 +128,8 @@ def deform_pack_weight(weight, groups):
     return packed
 
 
-def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None, bias=None, relu=False, mask=None, far_offsets=False):
+def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None, bias=None, relu=False, mask=None, far_offsets=False,
+                   table=None):
     """detectron2 DeformConv (3x3, dilation 1, deformable_groups 1) + fused FrozenBN affine / ReLU.
     x (N,C,H,W), offset (N,18,Ho,Wo), optional mask (N,9,Ho,Wo); returns (N,C,Ho,Wo) channels_last."""
     x = _nhwc(x)
@@ -146,10 +147,11 @@ def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.lib().wd_deform_conv3x3_hint_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
-                                                     C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
-                                                     C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad),
-                                                     C.c_int(1 if far_offsets else 0), _p(y), _stream()), 'wd_deform_conv3x3_f32')
+    _lib.check(_lib.lib().wd_deform_conv3x3_tab_f32(_p(x), _p(offset), _p(mask), _p(packed_weight), _p(scale), _p(bias),
+                                                    C.c_int(1 if relu else 0), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+                                                    C.c_int(c), C.c_int(groups), C.c_int(stride), C.c_int(pad),
+                                                    C.c_int(1 if far_offsets else 0), _p(table), _p(y), _stream()),
+               'wd_deform_conv3x3_f32')
     if log is not None:
         e1.record()
         fn = _lib.lib().wd_deform_conv3x3_variant
@@ -224,16 +226,24 @@ def tap_gemm_weight(weight, align=16):
     return w2
 
 
-def conv3x3_few(x, w2, bias, n_out, stride=1):
+def conv3x3_few(x, w2, bias, n_out, stride=1, deform_table=False):
     """3x3 conv, pad 1, with few output channels (the 18-channel deformable-offset conv) = one library GEMM over the
     input pixels (N = 9*n_out columns, full MFMA tiles) + the wd_tap_shift_add_f32 gather.  x (N,C,H,W) channels_last;
-    returns (N,n_out,Ho,Wo) channels_last."""
+    returns (N,n_out,Ho,Wo) channels_last.  deform_table=True (n_out 18, stride 1): the gather launch also emits the sampling
+    table of the persistent deformable kernel -> (offsets, table)."""
     x = _nhwc(x)
     n, c, h, w = x.shape
     a = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
     partial = torch.mm(a, w2.t())
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     out = torch.empty((n, n_out, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if deform_table:
+        assert n_out == 18 and stride == 1
+        lib = _lib.lib()
+        table = torch.empty(int(lib.wd_deform_table_bytes(C.c_int(n), C.c_int(h), C.c_int(w))), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.wd_deform_offsets_table_f32(_p(partial), C.c_int(w2.shape[0]), _p(bias), C.c_int(n), C.c_int(h), C.c_int(w),
+                                                   _p(out), _p(table), _stream()), 'wd_deform_offsets_table_f32')
+        return out, table
     _lib.check(_lib.lib().wd_tap_shift_add_f32(_p(partial), C.c_int(w2.shape[0]), C.c_int(n_out), _p(bias), C.c_int(n), C.c_int(h),
                                                C.c_int(w), C.c_int(stride), _p(out), _stream()), 'wd_tap_shift_add_f32')
     return out
