@@ -25,6 +25,9 @@
 namespace {
 
 constexpr int kMaxLevels = 8;
+#ifndef WD_ROI_QB
+#define WD_ROI_QB 8
+#endif
 
 struct Levels {
     const float* feat[kMaxLevels];
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(256) void roi_pool_row_kernel(Levels lv, int n_leve
                                                            int min_level, int canonical_level, float canonical_size,
                                                            float* __restrict__ out, int* __restrict__ fallback_flags,
                                                            const int* __restrict__ order) {
+    constexpr int QB = WD_ROI_QB;                   // footprint columns per pass (2 QB float4 loads in flight per lane)
     __shared__ float tabs[4][8][kMaxFoot];          // per wave: [0] = WY[ph], [1 + pw] = WX[pw]
     __shared__ int lohi[4][8][2];
     const int lane = threadIdx.x & 63;
@@ -377,28 +381,28 @@ __global__ __launch_bounds__(256) void roi_pool_row_kernel(Levels lv, int n_leve
         float4 bins[7];
 #pragma unroll
         for (int pw = 0; pw < 7; ++pw) bins[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q0 = 0; q0 < ncols; q0 += 8) {
-            float4 acc[8];
+        for (int q0 = 0; q0 < ncols; q0 += QB) {
+            float4 acc[QB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < QB; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int rr = ra; rr <= rb; rr += 2) {
                 const int r1 = (rr + 1 <= rb) ? rr + 1 : rb;
                 const float w0 = wy[rr], w1 = (rr + 1 <= rb) ? wy[r1] : 0.f;
-                float4 v0[8], v1[8];
+                float4 v0[QB], v1[QB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < QB; ++u) {
                     const int qq = (q0 + u < ncols) ? q0 + u : ncols - 1;
                     v0[u] = *reinterpret_cast<const float4*>(fc + ((size_t)rr * W + qq) * C);
                     v1[u] = *reinterpret_cast<const float4*>(fc + ((size_t)r1 * W + qq) * C);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < QB; ++u) {
                     acc[u].x += w0 * v0[u].x + w1 * v1[u].x; acc[u].y += w0 * v0[u].y + w1 * v1[u].y;
                     acc[u].z += w0 * v0[u].z + w1 * v1[u].z; acc[u].w += w0 * v0[u].w + w1 * v1[u].w;
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < QB; ++u) {
                 const int qq = (q0 + u < ncols) ? q0 + u : ncols - 1;
                 const bool ok = q0 + u < ncols;
 #pragma unroll
