@@ -245,7 +245,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v2_kernel(const float* __restr
         __syncthreads();
         read_half(0, 0);
         if (nslab > 1) sstore(1);
-        for (int s = 0; s < nslab; ++s) {
+        int s = 0;
+#ifndef WD_GEMM_NO_INTERLEAVE
+        // steady state (branch-free body): the loads / LDS reads / LDS writes are interleaved with the MFMAs of the same half by
+        // sched_group_barrier (one memory instruction per 4 MFMAs): issued in the matrix pipe's shadow instead of in front of it
+        for (; s + 2 < nslab; ++s) {
+            const int buf = s & 1;
+            gload(s + 2);
+            read_half(buf, 1);
+            WD_MFMA_HALF(0)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // 4 MFMA
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_half(buf ^ 1, 0);
+            WD_MFMA_HALF(1)
+            sstore(buf);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        for (; s < nslab; ++s) {                                // tail (and the whole loop with WD_GEMM_NO_INTERLEAVE)
             const int buf = s & 1;
             if (s + 2 < nslab) gload(s + 2);
             read_half(buf, 1);
