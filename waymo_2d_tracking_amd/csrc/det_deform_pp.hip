@@ -55,6 +55,9 @@ constexpr size_t SMEM = (size_t)BW_F * 4 + 4 * (size_t)PATCH_F * 4 + 2 * (size_t
 #ifndef PP_DMA_K
 #define PP_DMA_K 5
 #endif
+#ifndef PP_RES_TAPS
+#define PP_RES_TAPS 2       // (measured: 0 -> 100.3 us, 2 -> 98.2, 3 -> 98.7, 4 -> 98.2 on one box) taps whose weights stay in registers for the whole kernel (0..9); the others stream from LDS per tile
+#endif
 #ifdef PP_PROF
 __device__ unsigned long long pp_prof[8];      // experiments (reading the cycle counter drains the LDS queue: coarse only)
 #define PP_T0 long long _t = __builtin_readcyclecounter(); unsigned long long _acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -356,7 +359,9 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
 
     // ---- per-tap state ---------------------------------------------------------------------------------------------
     float a[8];                    // blended samples of the current tap (MFMA B operand)
-    float4 b[2][4];                // weights of tap k in b[k & 1] (MFMA A operand); tap 0's arrive in b[1] and are moved in G(0)
+    float4 b[2][4];                // weights of a streamed tap k in b[k & 1] (MFMA A operand)
+    constexpr int RW = PP_RES_TAPS;
+    float4 wres[RW > 0 ? RW : 1][4];   // weights of taps 0 .. RW-1: resident (fewer LDS reads per tap, no register move at tap 0)
     float4 cv[8];                  // the 4 corners x 2 quads of the tap being gathered
     float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;      // weights of the tap whose corners are in cv
     float cur_lh = 0.f, blend_lh = 0.f;                     // lh of the prepared / of the blended tap (>= FAR: global memory)
@@ -386,13 +391,15 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         ad0 = base + lane * 32; ad1 = ad0 + 2048; ad2 = ad0 + 4096; ad3 = ad0 + 6144;      // experiments: lane-linear corner reads
 #endif
     };
-    auto issue_reads = [&](int k, float4 (&bb)[4]) {                      // LDS: corners of the prepared tap + weights of tap k
+    auto issue_reads = [&](int k, float4 (&bb)[4], bool want_w) {          // LDS: corners of the prepared tap (+ weights of tap k)
         cv[0] = *reinterpret_cast<const float4*>(lds + ad0); cv[1] = *reinterpret_cast<const float4*>(lds + (ad0 ^ 16));
         cv[2] = *reinterpret_cast<const float4*>(lds + ad1); cv[3] = *reinterpret_cast<const float4*>(lds + (ad1 ^ 16));
         cv[4] = *reinterpret_cast<const float4*>(lds + ad2); cv[5] = *reinterpret_cast<const float4*>(lds + (ad2 ^ 16));
         cv[6] = *reinterpret_cast<const float4*>(lds + ad3); cv[7] = *reinterpret_cast<const float4*>(lds + (ad3 ^ 16));
+        if (want_w) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(my_bw + (k * 4 + j) * 256);
+            for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(my_bw + (k * 4 + j) * 256);
+        }
     };
     auto blend = [&]() {
 #ifdef PP_NO_BLEND
@@ -470,8 +477,10 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
             done[0] = acc[0] + acc[2]; done[1] = acc[1] + acc[3];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (RW == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[0][j] = b[1][j];        // tap 0's weights were requested into b[1] by M(8)
+                for (int j = 0; j < 4; ++j) b[0][j] = b[1][j];    // tap 0's weights were requested into b[1] by M(8)
+            }
         }
         blend_lh = cur_lh;
         blend();
@@ -509,9 +518,10 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         // up into the MFMA slot, which serialises the wave on LDS latency and defeats the two-team phase structure
         if (k == 7) PP_BARRIER();                                 // table of the next tile written -> readable (M(7) reads entry 0)
         // ---- M(k) ----
-        mfma_tap(b[k & 1]);
+        if constexpr (k < RW) mfma_tap(wres[k]);
+        else mfma_tap(b[k & 1]);
         constexpr int kn = (k + 1) % 9;
-        issue_reads(kn, b[(k + 1) & 1]);
+        issue_reads(kn, b[(k + 1) & 1], kn >= RW);
         read_entry((kn + 1) % 9);
         if (k == 6) PP_BARRIER();                                 // every wave has read entry 8 -> the table may be rewritten in G(7)
     };
@@ -520,7 +530,11 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     // first tap of the first tile: entry, addresses, corner + weight reads in flight before the loop
     read_entry(0);
     prep(base_cur);
-    issue_reads(0, b[1]);
+#pragma unroll
+    for (int k = 0; k < RW; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wres[k][j] = *reinterpret_cast<const float4*>(my_bw + (k * 4 + j) * 256);
+    issue_reads(0, b[1], RW == 0);
     read_entry(1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
