@@ -337,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
 
     TileXY prev = {0, 0, 0};
     bool prev_valid = false;
+    float4 aff_sc[2], aff_bi[2];                            // FrozenBN scale / shift of this lane's 2 x 4 output channels
     auto epilogue = [&]() {
         if (!prev_valid) return;
         const int ho = prev.ty * 8 + my_y, wo = prev.tx * 8 + my_x;
@@ -344,10 +345,14 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
             float* dst = y + ((long)prev.tn * HW + (long)ho * W + wo) * Cout + c0 + 4 * kq;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                // the affine lives in LDS: loads inside the loop would make the compiler wait for ALL vector memory
-                // operations (patch DMA, earlier stores) in front of every store
+                // the affine comes from LDS ONCE (registers afterwards): global loads inside the loop would make the compiler wait for
+                // ALL vector memory operations (patch DMA, earlier stores) in front of every store
+#ifdef PP_AFFINE_LDS
                 const float4 sc = *reinterpret_cast<const float4*>(affine + 16 * nt + 4 * kq);
                 const float4 bi = *reinterpret_cast<const float4*>(affine + 32 + 16 * nt + 4 * kq);
+#else
+                const float4 sc = aff_sc[nt], bi = aff_bi[nt];
+#endif
                 float4 v;
                 v.x = done[nt][0] * sc.x + bi.x; v.y = done[nt][1] * sc.y + bi.y;
                 v.z = done[nt][2] * sc.z + bi.z; v.w = done[nt][3] * sc.w + bi.w;
@@ -527,6 +532,13 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     };
 
     __syncthreads();
+#ifndef PP_AFFINE_LDS
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        aff_sc[nt] = *reinterpret_cast<const float4*>(affine + 16 * nt + 4 * kq);
+        aff_bi[nt] = *reinterpret_cast<const float4*>(affine + 32 + 16 * nt + 4 * kq);
+    }
+#endif
     // first tap of the first tile: entry, addresses, corner + weight reads in flight before the loop
     read_entry(0);
     prep(base_cur);
