@@ -1,3 +1,4 @@
+# build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probe/lds_bank_probe tools/probe/lds_bank_probe.hip
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
