@@ -1,5 +1,5 @@
-# build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probe/lds_bank_probe tools/probe/lds_bank_probe.hip
 #!/bin/bash
+# build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probe/lds_bank_probe tools/probe/lds_bank_probe.hip
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/pmcprobe
