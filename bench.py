@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA = vector peak
+F64_VALU_PEAK_GFLOPS = 78600.0  # f64 vector FMA rate = half the f32 vector rate (CDNA4 public figure; the guide only lists f32)
 
 
 def parse_args():
@@ -43,7 +44,8 @@ def parse_args():
     ap.add_argument('--frames-per-step', type=int, default=10, help='e2e/detect: frames per step (multiple of 5)')
     ap.add_argument('--tta', default='', help="e2e/detect: test-time augmentation of the detector pass, e.g. x1.5,hflip (config 4)")
     ap.add_argument('--collate', action='store_true',
-                    help='e2e: gather every chunk\'s track rows to rank 0 inside the timed region (the submission collation over RCCL)')
+                    help='e2e: run the per-chunk birth-count exchange + row-block gather to rank 0 also with one rank '
+                         '(always on when N > 1 or WT_FORCE_DIST=1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--inflight', type=int, default=1,
                     help='e2e/detect: frames in flight (hipGraph lanes on separate streams); EXPERIMENT: 2 deadlocks at 1920x1280 (spin-waiting library kernels)')
@@ -52,16 +54,35 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: the parent starts the N ranks itself (one fresh process per GPU, the
+    way the reference's Tester starts its workers, detnet/trainer/test.py:227-255) BEFORE anything touches the GPU, waits,
+    and exits with the children's status.  Under torchrun (WORLD_SIZE set) this is a no-op."""
+    if 'WORLD_SIZE' in os.environ or args.gpus <= 1:
+        return
+    from waymo_2d_tracking_amd import launcher
+    try:
+        rc = launcher.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+    except launcher.LaunchError as e:
+        raise SystemExit('bench.py --gpus %d: %s' % (args.gpus, e))
+    raise SystemExit(rc)
+
+
 def init_dist(args):
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and 'WORLD_SIZE' in os.environ and args.gpus != 1:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist_on = world > 1 or os.environ.get('WT_FORCE_DIST') == '1'       # WT_FORCE_DIST: exercise RCCL with one rank
     torch.cuda.set_device(local if dist_on else 0)
     if dist_on:
         import torch.distributed as dist
+        if torch.cuda.device_count() <= local:
+            raise SystemExit('bench.py: rank %d needs GPU %d but only %d visible' % (rank, local, torch.cuda.device_count()))
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        world = dist.get_world_size()                # what RCCL actually connected, not what the flag says
     return world, rank, local
 
 
@@ -71,6 +92,26 @@ def _dist_on():
         return dist.is_available() and dist.is_initialized()
     except ImportError:
         return False
+
+
+def rccl_ranks():
+    """The rank numbers as an actual all_gather over the initialised backend reports them (None without a process group)."""
+    if not _dist_on():
+        return None
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device='cuda')
+    seen = torch.zeros(dist.get_world_size(), dtype=torch.int64, device='cuda')
+    dist.all_gather_into_tensor(seen, mine)
+    return [int(v) for v in seen.cpu().tolist()]
+
+
+def exchange_counts(counts_dev, all_counts_dev):
+    """Per-step birth-count exchange of the sharded stages (ids of rank r start after the births of ranks < r): one
+    all_gather of the device-side (rows, births) pair, stream-ordered, no host synchronisation."""
+    if _dist_on():
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(all_counts_dev, counts_dev)
 
 
 def barrier_sync(world):
@@ -138,7 +179,14 @@ def stage_track(args, world, rank):
     trk = DeviceTracker(packed, ithr, 2, 0, sthr)
     steps = args.steps or 20
     warmup = args.warmup if args.warmup is not None else 3
-    dt, ev_ms = timed_steps(world, trk.run, steps, warmup)
+    import torch
+    all_counts = torch.zeros(2 * world, dtype=torch.int64, device='cuda')
+
+    def step():
+        trk.run()
+        exchange_counts(trk.counts, all_counts)
+
+    dt, ev_ms = timed_steps(world, step, steps, warmup)
     out, births = trk.results()
     n_frames = trk.n_frames
     # algorithmic bytes: per class-frame 20 N + 896 T + 912 K + 8 N T + 48 K_out ; approximated with the
@@ -148,16 +196,21 @@ def stage_track(args, world, rank):
     cls_frames = n_frames * 3
     nt = (n_dets / cls_frames) * (rows / cls_frames) * cls_frames
     alg_bytes = 20.0 * n_dets + 896.0 * rows + 912.0 * rows + 8.0 * nt + 48.0 * rows
+    sort_flops = 21.0 * nt + 2.0 * 343 * 3 * 2 * rows
     res = dict(value=n_frames * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps,
                workload='SORT on pre-computed detections: %d segments x 5 cameras x 198 frames/GPU, ~100 boxes/frame, '
                         'max_age 2, min_hits 0, all boxes tracked' % args.segments,
                dtype='f64',
-               roofline=dict(bound='hbm', kernel='sort_streams_kernel', achieved=alg_bytes / (ev_ms / steps * 1e-3) / 1e9,
-                             peak=HBM_PEAK_GBS, unit='GB/s', traffic=None,
-                             note='serial-dependency bound control loop (Kalman/Munkres per frame); HBM fraction is '
-                                  'reported for completeness, not as the limiter'),
-               extra=dict(n_dets=n_dets, n_rows=rows, n_births=births, n_frames=n_frames))
-    res['roofline']['frac'] = res['roofline']['achieved'] / HBM_PEAK_GBS
+               roofline=dict(bound='latency', kernel='sort_streams_kernel',
+                             achieved=sort_flops / (ev_ms / steps * 1e-3) / 1e9, peak=F64_VALU_PEAK_GFLOPS, unit='GFLOP/s f64',
+                             traffic=None, hbm_gbs=alg_bytes / (ev_ms / steps * 1e-3) / 1e9,
+                             note='a serial per-frame control loop (Kalman, Munkres) on one wave per tracker: bound by '
+                                  'dependent-instruction / LDS latency, neither by HBM nor by the f64 ALU rate; both '
+                                  'fractions are reported for completeness (flops: 21 per IoU pair + 2x7x7x7x3 per '
+                                  'Kalman predict/update + Munkres passes not counted)'),
+               extra=dict(n_dets=n_dets, n_rows=rows, n_births=births, n_frames=n_frames,
+                          births_by_rank=all_counts.view(-1, 2)[:, 1].cpu().tolist() if _dist_on() else None))
+    res['roofline']['frac'] = res['roofline']['achieved'] / F64_VALU_PEAK_GFLOPS
     if rank == 0 and not args.no_verify:
         # checker, outside the timed region: the rows of the timed call replayed through the CPU oracle
         from oracle import oracle as O
@@ -227,14 +280,19 @@ def stage_ensemble(args, world, rank):
     warmup = args.warmup if args.warmup is not None else 3
     dt, ev_ms = timed_steps(world, ens.run, steps, warmup)
     alg_bytes = 80.0 * len(d)            # read 40 n + write 40 n per group
+    gsz = np.diff(off).astype(np.float64)
+    pair_flops = float((17.0 * gsz * (gsz - 1) / 2).sum())
     res = dict(value=args.images * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps,
                workload='soft-NMS ensemble of K=%d inputs, %d images/GPU, 100 objects/image, 3 classes, thr .5 cut .9'
                         % (args.k_inputs, args.images),
                dtype='f64',
-               roofline=dict(bound='hbm', kernel='ensemble_groups_kernel', achieved=alg_bytes / (ev_ms / steps * 1e-3) / 1e9,
-                             peak=HBM_PEAK_GBS, unit='GB/s', traffic=None),
+               roofline=dict(bound='latency', kernel='softnms_fast_kernel',
+                             achieved=pair_flops / (ev_ms / steps * 1e-3) / 1e9, peak=F64_VALU_PEAK_GFLOPS, unit='GFLOP/s f64',
+                             traffic=None, hbm_gbs=alg_bytes / (ev_ms / steps * 1e-3) / 1e9,
+                             note='O(n^2) f64 pair work with two f64 divisions per overlapping pair, 39 rows per group on '
+                                  'average: latency / division-throughput bound; 17 flops per ordered pair counted'),
                extra=dict(n_rows=int(len(d)), n_groups=int(len(off) - 1)))
-    res['roofline']['frac'] = res['roofline']['achieved'] / HBM_PEAK_GBS
+    res['roofline']['frac'] = res['roofline']['achieved'] / F64_VALU_PEAK_GFLOPS
     if rank == 0 and not args.no_verify:
         import torch
         from oracle import oracle as O
@@ -301,6 +359,7 @@ def cpu_baseline_e2e(pipe, track, height=448, width=640):
 
 def main():
     args = parse_args()
+    launch_if_needed(args)         # no GPU call before this line
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
@@ -330,10 +389,13 @@ def main():
             res['cpu_baseline'] = cpu_baseline_e2e(pipe, args.stage == 'e2e')
         metric = 'end-to-end frames/sec (detect+SORT) on 1920x1280 Waymo frames' if args.stage == 'e2e' else \
             'detector frames/sec on 1920x1280 Waymo frames'
+    ranks_seen = rccl_ranks()
     if _dist_on():
         import torch.distributed as dist
         dist.barrier()
     if rank == 0:
+        if ranks_seen is not None:
+            res.setdefault('extra', {})['rccl_ranks'] = ranks_seen
         line = {'metric': metric, 'value': res['value'], 'unit': res['unit'], 'n_gpus': world, 'steps': steps,
                 'warmup': warmup, 'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': res['dtype'], 'data': 'synthetic',

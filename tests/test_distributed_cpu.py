@@ -136,3 +136,86 @@ def test_splits():
     assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
     assert D.balanced_stream_split([5, 1, 1, 1], 2) == [(0, 1), (1, 4)]
     assert D.balanced_stream_split([3], 4)[-1] == (1, 1) or sum(e - s for s, e in D.balanced_stream_split([3], 4)) == 1
+
+
+def _row_collator_worker(rank, world_size, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    from waymo_2d_tracking_amd import distributed as D
+    spec = [('frame', torch.int64, ()), ('local_id', torch.int64, ()), ('bbox', torch.float64, (4,)), ('score', torch.float64, ()),
+            ('category', torch.int32, ())]
+    col = D.DeviceRowCollator(spec, 11, 3, 'cpu')                # capacity 11 rows: the int32 column needs padding to 8 bytes
+    for b in range(3):
+        k = 2 + 3 * rank + b                                     # ragged: every (rank, block) another row count
+        v = col.columns(b)
+        v['frame'][:k] = torch.arange(k) + 100 * rank + 10 * b
+        v['bbox'][:k] = rank + 0.25 * b
+        v['category'][:k] = 1 + rank
+        v['score'][:k] = 0.5
+        v['local_id'][:k] = torch.arange(k)
+        col.counts[b, 0] = k
+        col.counts[b, 1] = 7 * (rank + 1) + b                    # births
+        col.exchange(b)
+    if rank == 0:
+        rep = []
+        for b in range(3):
+            parts, counts = col.decode(b)
+            assert counts.tolist() == [[2 + b, 7 + b], [5 + b, 14 + b]]
+            for r in range(2):
+                k = 2 + 3 * r + b
+                assert parts[r]['frame'].tolist() == [i + 100 * r + 10 * b for i in range(k)]
+                assert parts[r]['bbox'].shape == (k, 4) and (parts[r]['bbox'] == r + 0.25 * b).all()
+                assert parts[r]['category'].dtype == np.int32 and (parts[r]['category'] == 1 + r).all()
+            rep.append(counts.tolist())
+        json.dump(rep, open(os.path.join(out_dir, 'ok.json'), 'wt'))
+    else:
+        assert col.collated is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_device_row_collator_world2(tmp_path):
+    """The per-step exchange of the sharded detect+track bench (birth-count all_gather + ONE block gather, no host staging,
+    fixed capacity, valid counts travelling next to the rows) under gloo, world size 2."""
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_row_collator_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert len(json.load(open(tmp_path / 'ok.json'))) == 3
+
+
+def test_launcher_environment_and_refusal(tmp_path):
+    """bench.py --gpus N: the parent starts N children itself (reference: detnet/trainer/test.py:227-255)."""
+    from waymo_2d_tracking_amd import launcher as L
+    envs = L.rank_environments(4, 23456, base_env={'PATH': '/usr/bin', 'WORLD_SIZE': 'junk'})
+    assert [e['RANK'] for e in envs] == ['0', '1', '2', '3'] and [e['LOCAL_RANK'] for e in envs] == ['0', '1', '2', '3']
+    assert all(e['WORLD_SIZE'] == '4' and e['MASTER_ADDR'] == '127.0.0.1' and e['MASTER_PORT'] == '23456' for e in envs)
+    assert all(e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and e['PATH'] == '/usr/bin' for e in envs)
+    import pytest
+    with pytest.raises(L.LaunchError, match='only 1 GPU'):
+        L.spawn_local_ranks([sys.executable, '-c', 'pass'], 2, n_devices=1)      # never oversubscribe a GPU
+    with pytest.raises(L.LaunchError):
+        L.spawn_local_ranks([sys.executable, '-c', 'pass'], 0, n_devices=8)
+    # children really run, each with its own rank; all succeed -> 0
+    code = ("import os; open(os.path.join(%r, 'r' + os.environ['RANK']), 'wt').write(os.environ['WORLD_SIZE'] + ' ' + "
+            "os.environ['LOCAL_RANK'] + ' ' + os.environ['MASTER_PORT'])" % str(tmp_path))
+    assert L.spawn_local_ranks([sys.executable, '-c', code], 3, n_devices=3) == 0
+    got = [open(tmp_path / ('r%d' % r)).read().split() for r in range(3)]
+    assert [g[:2] for g in got] == [['3', '0'], ['3', '1'], ['3', '2']] and len({g[2] for g in got}) == 1
+    # one failing rank -> its exit code, the sleeping ranks are stopped (not waited for)
+    code = "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(600)"
+    import time
+    t0 = time.time()
+    assert L.spawn_local_ranks([sys.executable, '-c', code], 2, n_devices=2) == 7
+    assert time.time() - t0 < 60
+
+
+def test_bench_gpus_flag_refuses_without_gpus():
+    """`python bench.py --gpus 8` with fewer GPUs exits non-zero BEFORE any GPU call and never prints a JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8'], env=env, capture_output=True, text=True,
+                       timeout=300)
+    if torch.cuda.device_count() >= 8:
+        return
+    assert p.returncode != 0 and 'GPU(s) visible' in (p.stderr + p.stdout) and '"metric"' not in p.stdout

@@ -71,13 +71,19 @@ class DetectTrackPipeline(object):
         self.n_dets_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.use_graph, self._graph = use_graph, None
         self.n_inflight, self._lanes, self._frame_no = max(1, n_inflight), [], 0
-        # per-chunk tracker output rows
-        self.out_frame = torch.zeros((R, n + 1), dtype=torch.int64, device=self.dev)
-        self.out_cat = torch.zeros((R, n + 1), dtype=torch.int32, device=self.dev)
-        self.out_bbox = f64(R, n + 1, 4)
-        self.out_score = f64(R, n + 1)
-        self.out_id = torch.zeros((R, n + 1), dtype=torch.int64, device=self.dev)
-        self.chunk_counts = torch.zeros((R, 2), dtype=torch.int64, device=self.dev)
+        # per-chunk tracker output rows: ONE contiguous byte block per chunk (the columns are typed views of it), so the
+        # collation of a chunk to rank 0 is a gather of that block as it lies in HBM (distributed.DeviceRowCollator)
+        from . import distributed as D
+        self.rows = D.DeviceRowCollator([('frame', torch.int64, ()), ('local_id', torch.int64, ()), ('bbox', torch.float64, (4,)),
+                                         ('score', torch.float64, ()), ('category', torch.int32, ())], n + 1, R, self.dev)
+        views = [self.rows.columns(c) for c in range(R)]
+        self.out_frame = [v['frame'] for v in views]
+        self.out_cat = [v['category'] for v in views]
+        self.out_bbox = [v['bbox'] for v in views]
+        self.out_score = [v['score'] for v in views]
+        self.out_id = [v['local_id'] for v in views]
+        self.chunk_counts = self.rows.counts
+        self.collate = False           # exchange birth counts + gather the chunk's rows to rank 0 behind every track() call
         self.frame_off = (torch.arange(self.n_frames + 1, dtype=torch.int64) * SLOTS).to(self.dev)
         self.stream_off = (torch.arange(n_cameras + 1, dtype=torch.int64) * frames_per_camera).to(self.dev)
         self.clip_w = torch.full((n_cameras,), float(width), dtype=torch.float64, device=self.dev)
@@ -125,7 +131,7 @@ class DetectTrackPipeline(object):
                     self._detect_core(lane['gin'])
             lane['stream'].synchronize()
             lane['graph'] = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream']):
+            with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream'], capture_error_mode='thread_local'):
                 lane['gout'] = self._detect_core(lane['gin'])
             self._lanes.append(lane)
         torch.cuda.synchronize()
@@ -206,25 +212,19 @@ class DetectTrackPipeline(object):
                 for ev in done:
                     self.track_stream.wait_event(ev)             # ... on every lane
                 self.track(c)                                    # SORT of chunk c runs under the detector pass of chunk c + 1
+                if self.collate:
+                    self.rows.exchange(c)                        # (rows, births) all_gather + block gather, stream-ordered
                 self._slot_done[c] = torch.cuda.Event()
                 self._slot_done[c].record(self.track_stream)
         self.chunk += 1
         self.time = (self.time + self.fpc) % self.n_times
         return None
 
-    def collate_last_chunk(self):
-        """Optional timed leg (bench.py --collate): the rows of the chunk tracked LAST step travel to rank 0 the way the CLIs
-        collate a submission (distributed.gather_columns_rank0: counts all_gather + one padded tensor gather over RCCL).  The
-        previous chunk is used so that the gather overlaps the SORT of the current one."""
-        from . import distributed as D
-        c = self.chunk - 2
-        if c < 0:
-            return None
-        k = int(self.chunk_counts[c, 0].item())
-        cols = dict(frame=self.out_frame[c, :k].cpu().numpy(), category=self.out_cat[c, :k].cpu().numpy(),
-                    bbox=self.out_bbox[c, :k].cpu().numpy(), score=self.out_score[c, :k].cpu().numpy(),
-                    local_id=self.out_id[c, :k].cpu().numpy())
-        return D.gather_columns_rank0(cols)
+    def collated(self, c):
+        """Rank 0, after the device is idle: what `exchange(c)` delivered - per rank the rows of chunk c and the
+        (rows, births) table of all ranks."""
+        torch.cuda.synchronize()
+        return self.rows.decode(c)
 
     def history(self):
         """Synchronise and return what the trackers of the CURRENT segment consumed and produced so far:
@@ -259,11 +259,11 @@ class DetectTrackPipeline(object):
         fr, ct, bb, sc, lid, st = [], [], [], [], [], []
         for c in range(nch):
             k = int(counts[c, 0])
-            f = self.out_frame[c, :k]
+            f = self.out_frame[c][:k]
             s = torch.div(f, F, rounding_mode='floor')
             fr.append(s * (nch * F) + c * F + (f - s * F)); st.append(s)
-            ct.append(self.out_cat[c, :k]); bb.append(self.out_bbox[c, :k]); sc.append(self.out_score[c, :k])
-            lid.append(self.out_id[c, :k])
+            ct.append(self.out_cat[c][:k]); bb.append(self.out_bbox[c][:k]); sc.append(self.out_score[c][:k])
+            lid.append(self.out_id[c][:k])
         fr, st, ct, bb, sc, lid = [torch.cat(v) for v in (fr, st, ct, bb, sc, lid)]
         gid = self.tracker.global_ids(st, lid, 0)
         order = torch.sort(st, stable=True)[1]                   # chunk-major -> stream-major (utils.py output order)
@@ -283,6 +283,36 @@ def check_against(pipe, track_streams):
           and np.array_equal(rows['bbox'], ref['bbox']) and np.allclose(rows['score'], ref['score'], rtol=4e-16, atol=0))
     return dict(ok=bool(ok), chunks=pipe.chunk, frames=int(packed['frame_det_offsets'].size - 1), dets=int(packed['x'].size),
                 rows=int(len(rows['frame'])), rows_ref=int(len(ref['frame'])), births=births, births_ref=int(ref['n_births']))
+
+
+def collation_report(pipe, world, rank):
+    """After the timed region: what the per-step exchange delivered.  `rccl_ranks` comes from an actual all_gather of the
+    rank numbers; on rank 0 the gathered block of rank 0 must equal its own rows and every rank's row count must equal the
+    count that rank published."""
+    import torch.distributed as dist
+    rep = dict(collation='all_gather(rows, births) + one block gather per chunk, device-resident', exchanges=pipe.rows.exchanges)
+    if dist.is_available() and dist.is_initialized():
+        mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=pipe.dev)
+        seen = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=pipe.dev)
+        dist.all_gather_into_tensor(seen, mine)
+        rep['rccl_ranks'] = [int(v) for v in seen.cpu().tolist()]
+        rep['backend'] = dist.get_backend()
+    if rank == 0:
+        nch = pipe.chunk
+        rows_by_rank = np.zeros(world, np.int64)
+        births_by_rank = np.zeros(world, np.int64)
+        own_ok = True
+        for c in range(nch):
+            parts, counts = pipe.collated(c)
+            rows_by_rank += counts[:, 0]
+            births_by_rank += counts[:, 1]
+            k = int(pipe.chunk_counts[c, 0].item())
+            own = {n: v[:k].cpu().numpy() for n, v in pipe.rows.columns(c).items()}
+            own_ok = own_ok and all(np.array_equal(parts[0][n], own[n]) for n in own) and \
+                all(len(parts[r]['frame']) == int(counts[r, 0]) for r in range(world))
+        rep.update(collated_chunks=nch, collated_rows_by_rank=rows_by_rank.tolist(), births_by_rank=births_by_rank.tolist(),
+                   id_offsets=np.concatenate([[0], np.cumsum(births_by_rank)[:-1]]).tolist(), collated_ok=bool(own_ok))
+    return rep
 
 
 def _pmc_traffic(tag):
@@ -319,11 +349,14 @@ def run(args, world, rank, timed_steps):
         # step share the chip with the SORT kernel of the previous chunk); the other frames replay the captured hipGraph of the
         # same launches
         pipe.step(track, instrument=ops.EVENT_LOG is not None)
-        if track and getattr(args, 'collate', False):
-            got = pipe.collate_last_chunk()
-            if got is not None:
-                state['collated_rows'] = state.get('collated_rows', 0) + len(got['frame'])
 
+    # N > 1 (or --collate / WT_FORCE_DIST=1): behind every chunk's SORT the (rows, births) pairs of all ranks are exchanged
+    # (all_gather: the id offsets of the sharded sequences) and the chunk's rows travel to rank 0 in ONE gather of the block as
+    # it lies in HBM - the single RCCL collation step north_star names, stream-ordered, no host synchronisation
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    pipe.collate = track and (dist_on or getattr(args, 'collate', False))
+    if pipe.use_graph:
+        pipe._capture()            # capture before any collective is in flight
     dt, ev_ms = timed_steps(world, step, steps, warmup)
     log, ops.EVENT_LOG = ops.EVENT_LOG or [], None
     torch.cuda.synchronize()
@@ -353,8 +386,9 @@ def run(args, world, rank, timed_steps):
                         % (', --tta ' + args.tta if getattr(args, 'tta', '') else '',
                            'SORT (max_age 2, min_hits 0, all boxes tracked; trackers resident for the whole segment)' if track else 'no tracking', 5, fps),
                roofline=roofline,
-               extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_total / max(1, frames * state['n']), hip_graph=pipe._graph is not None, track_rows=n_out, births=births,
-                          collated_rows_rank0=state.get('collated_rows')))
+               extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_total / max(1, frames * state['n']), hip_graph=pipe._graph is not None, track_rows=n_out, births=births))
+    if pipe.collate:
+        res['extra'].update(collation_report(pipe, world, rank))
     res['pipeline'] = pipe         # bench.py times the CPU port (oracle) against the same parameters
     return res, steps, warmup
 

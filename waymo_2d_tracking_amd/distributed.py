@@ -107,6 +107,74 @@ def gather_columns_rank0(columns):
     return {k: np.concatenate(v) for k, v in out.items()}
 
 
+class DeviceRowCollator(object):
+    """Collation of fixed-capacity row blocks that already live in HBM: the per-step exchange of the sharded detect+track path.
+
+    Every rank owns, per chunk, ONE contiguous byte block holding its output columns (views of that block are what the SORT
+    kernel writes into) and a device-side (rows, births) pair.  `exchange` enqueues on the CURRENT stream
+      * an all_gather of the (rows, births) pairs - the birth-count exchange: ids of rank r start after the births of ranks < r
+        (the reference's process-global counter, tracking/sort/sort.py:86), and
+      * ONE gather of the byte blocks to rank 0 (RCCL over xGMI with backend "nccl", gloo in the CPU tests)
+    without any host synchronisation or host staging: nothing is read back, the valid row counts travel next to the rows and
+    rank 0 trims when it decodes (`decode`).  Column layout inside a block: [col0 capacity rows | col1 ... ], 8-byte aligned."""
+
+    def __init__(self, spec, capacity, n_blocks, device):
+        import torch
+        self.w, self.r = world()
+        self.spec, self.capacity = [], int(capacity)
+        o = 0
+        for name, dtype, trailing in spec:
+            nbytes = torch.empty(0, dtype=dtype).element_size() * int(np.prod(trailing, dtype=np.int64)) * self.capacity
+            self.spec.append((name, dtype, tuple(trailing), o, nbytes))
+            o += (nbytes + 7) // 8 * 8
+        self.block_bytes = o
+        self.blocks = torch.zeros((n_blocks, o), dtype=torch.uint8, device=device)
+        self.counts = torch.zeros((n_blocks, 2), dtype=torch.int64, device=device)
+        self.all_counts = torch.zeros((n_blocks, self.w, 2), dtype=torch.int64, device=device)
+        self.collated = torch.zeros((n_blocks, self.w, o), dtype=torch.uint8, device=device) if (self.r == 0 and self.w > 1) else None
+        self.exchanges = 0
+
+    def columns(self, b):
+        """Typed views of block b (what the producer writes into)."""
+        return self._views(self.blocks[b])
+
+    def _views(self, raw):
+        out = {}
+        for name, dtype, trailing, o, nbytes in self.spec:
+            out[name] = raw[o:o + nbytes].view(dtype).reshape((self.capacity,) + trailing)
+        return out
+
+    def exchange(self, b):
+        self.exchanges += 1
+        if self.w == 1 and not _initialized():
+            return
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(self.all_counts[b].reshape(-1), self.counts[b])
+        if self.w == 1:
+            return
+        if self.r == 0:
+            dist.gather(self.blocks[b], [self.collated[b, k] for k in range(self.w)], dst=0)
+        else:
+            dist.gather(self.blocks[b], None, dst=0)
+
+    def decode(self, b):
+        """Rank 0, after a synchronisation: per rank the trimmed numpy columns of block b + the (rows, births) table."""
+        if self.w == 1:
+            k = int(self.counts[b, 0].item())
+            return [{n: v[:k].cpu().numpy() for n, v in self.columns(b).items()}], self.counts[b:b + 1].cpu().numpy()
+        counts = self.all_counts[b].cpu().numpy()
+        return [{n: v[:int(counts[k, 0])].cpu().numpy() for n, v in self._views(self.collated[b, k]).items()}
+                for k in range(self.w)], counts
+
+
+def _initialized():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except ImportError:
+        return False
+
+
 def all_gather_int(value):
     w, r = world()
     if w == 1:

@@ -1,0 +1,94 @@
+"""One process per GPU, started by the parent itself - the way the reference starts its N inference workers
+(/root/reference/detnet/trainer/test.py:227-255: one spawned process per dataset split, `cuda_device_id = i % n_gpu`;
+detnet/trainer/launch.sh:3-9 for the training side).
+
+`spawn_local_ranks` is used by `bench.py --gpus N` (and by the CLIs' `-j N`) when no launcher set WORLD_SIZE: the parent
+must not have touched the GPU (no HIP call, no `torch.cuda.is_available()`): it only counts devices (which does not
+initialise the runtime on this image), starts N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT in their environment, forwards their output, and fails if any child fails.  Children are plain
+`subprocess` children of a parent that never initialised HIP - no fork of GPU state, no exec from a GPU process.
+"""
+import os
+import socket
+import subprocess
+import sys
+import time
+
+
+class LaunchError(RuntimeError):
+    pass
+
+
+def free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    """Number of GPUs this process could use, without initialising the HIP runtime."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def rank_environments(n_ranks, port, base_env=None):
+    """The environment of every child: torchrun's variables for a single node, rendezvous on 127.0.0.1 (the
+    container's hostname may not resolve)."""
+    base = dict(os.environ if base_env is None else base_env)
+    envs = []
+    for r in range(n_ranks):
+        e = dict(base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                 MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WT_LAUNCHED_BY='waymo_2d_tracking_amd.launcher')
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this pool (RCCL needs it)
+        e.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n_ranks)))
+        envs.append(e)
+    return envs
+
+
+def spawn_local_ranks(argv, n_ranks, port=None, n_devices=None, poll_s=0.2, timeout_s=None):
+    """Start `n_ranks` children running `argv` (e.g. [sys.executable, 'bench.py', '--gpus', '8', ...]), one per GPU.
+    Returns 0 when every child exits 0.  Raises LaunchError before starting anything when fewer than n_ranks GPUs are
+    visible; returns the first non-zero exit code (after terminating the remaining children) when a child fails."""
+    if n_ranks < 1:
+        raise LaunchError('--gpus must be >= 1, got %d' % n_ranks)
+    have = visible_gpus() if n_devices is None else n_devices
+    if have < n_ranks:
+        raise LaunchError('%d ranks requested but only %d GPU(s) visible: refusing to oversubscribe a GPU '
+                          '(one process per GPU)' % (n_ranks, have))
+    port = port or free_port()
+    procs = [subprocess.Popen(list(argv), env=e) for e in rank_environments(n_ranks, port)]
+    t0 = time.time()
+    rc = 0
+    try:
+        live = set(range(n_ranks))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    sys.stderr.write('launcher: rank %d exited with code %d; stopping the other ranks\n' % (r, code))
+            if rc != 0:
+                break
+            if timeout_s is not None and time.time() - t0 > timeout_s:
+                rc = 124
+                sys.stderr.write('launcher: timeout after %.0f s\n' % timeout_s)
+                break
+            if live:
+                time.sleep(poll_s)
+    finally:
+        for p in procs:                                          # exact PIDs we started, never a pattern
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
