@@ -269,3 +269,24 @@ def test_detections_to_wire_tta_scaling():
     assert [round(v, 5) for v in score.tolist()] == [0.12346, 0.99999] and cat.tolist() == [1, 4]
     same, _, _ = detections_to_wire(boxes, scores, classes, 2880, 1920)
     assert same.tolist() == [[150.0, 300.0, 300.0, 300.0], [0.0, 0.0, 2880.0, 1920.0]]
+
+
+def test_image_loader_reports_original_size_and_contrast_precedes_resize(tmp_path):
+    """detnet/inference.py:170-178 (ToRGB, AutoContrast, Resize) and export.py:159-165 -> coco.py:243-246: exported boxes are
+    scaled by the ORIGINAL image size, and with --auto-contrast --resize the contrast stretch sees the unresized pixels."""
+    from PIL import Image, ImageOps
+    from waymo_2d_tracking_amd.detnet.inference import ImageLoader, resize_size
+    rng = np.random.default_rng(3)
+    arr = rng.integers(40, 200, (60, 90, 3), dtype=np.uint8)
+    path = str(tmp_path / 'a.png')
+    Image.fromarray(arr).save(path)
+    plain, size = ImageLoader([], resize=None)._decode(path)
+    assert size == (90, 60) and np.array_equal(plain, arr)
+    ld = ImageLoader([], resize=30, auto_contrast=True)
+    assert ld.auto_contrast_in_loader
+    got, size = ld._decode(path)
+    assert size == (90, 60)                                       # not the resized (45, 30)
+    oh, ow = resize_size(90, 60, 30)
+    exp = np.asarray(ImageOps.autocontrast(Image.fromarray(arr)).resize((ow, oh), Image.BILINEAR))
+    assert got.shape == (30, 45, 3) and np.array_equal(got, exp)
+    assert not ImageLoader([], resize=None, auto_contrast=True).auto_contrast_in_loader      # GPU autocontrast_ then

@@ -166,8 +166,15 @@ int wd_gemm_lt_f32(const float* a, const float* w, const float* bias, const floa
             (void)hipEventDestroy(e1);
             WT_HIP(hipStreamSynchronize(stream));
             p.best_us = best * 1e3f / 3.f;
-            p.tuned = true;
         }
+        // the choice is final once it was made outside a capture (also when the heuristic offered a single candidate);
+        // a first call inside a capture keeps the heuristic's pick for this call and decides at the next eager call
+        if (cap == hipStreamCaptureStatusNone) p.tuned = true;
+    }
+    if (p.ws > (workspace ? workspace_bytes : 0)) {
+        wt::set_error("wd_gemm_lt_f32: the cached algorithm for %dx%dx%d needs %zu workspace bytes, %zu passed", m, n, k,
+                      (size_t)p.ws, workspace ? workspace_bytes : (size_t)0);
+        return WT_ERR_INVALID;
     }
     return run(p, p.algo, a, w, bias, c, out, beta, workspace, workspace_bytes, stream);
 }

@@ -157,19 +157,29 @@ def resize_size(w, h, size, max_size=None):
 class ImageLoader(object):
     """Decode ahead of the GPU: PIL decode + ToRGB (+ Resize, PIL bilinear like the reference) in a thread pool, pinned
     staging buffer, asynchronous H2D of the uint8 HWC image (7.4 MB per 1920x1280 frame).  Yields
-    (image_id, device uint8 (H, W, 3), (width, height) of the image handed to the detector)."""
+    (image_id, device uint8 (H, W, 3), (width, height) of the ORIGINAL decoded image): the detector's boxes are normalised,
+    and the reference's export scales them by the untransformed data set's image size (export.py:159-165 ->
+    coco.py:243-246 with `dataset.dataset`), not by the resized one.
 
-    def __init__(self, items, resize=None, max_image_size=None, workers=4, depth=4):
+    Transform order of the reference (detnet/inference.py:170-178): ToRGB, AutoContrast, [CLAHE], Resize.  Without --resize
+    AutoContrast runs on the GPU (autocontrast_, bit-exact with PIL); with --resize it has to precede the resize, so the
+    loader thread applies PIL's own ImageOps.autocontrast before resizing (`auto_contrast_in_loader`)."""
+
+    def __init__(self, items, resize=None, max_image_size=None, workers=4, depth=4, auto_contrast=False):
         self.items, self.resize, self.max_size = items, resize, max_image_size
         self.workers, self.depth = workers, depth
+        self.auto_contrast_in_loader = bool(auto_contrast and resize)
 
     def _decode(self, path):
-        from PIL import Image
+        from PIL import Image, ImageOps
         img = Image.open(path).convert('RGB')                                       # ToRGB (vision.py:954)
+        size = img.size
+        if self.auto_contrast_in_loader:
+            img = ImageOps.autocontrast(img)                                        # AutoContrast precedes Resize
         if self.resize:
             oh, ow = resize_size(img.width, img.height, int(self.resize), self.max_size)
             img = img.resize((ow, oh), Image.BILINEAR)
-        return np.asarray(img, dtype=np.uint8)
+        return np.asarray(img, dtype=np.uint8), size
 
     def __iter__(self):
         from concurrent.futures import ThreadPoolExecutor
@@ -185,9 +195,9 @@ class ImageLoader(object):
                 nxt = next(it, None)
                 if nxt is not None:
                     pending.append((nxt[0], pool.submit(self._decode, nxt[1])))
-                arr = fut.result()
+                arr, size = fut.result()
                 t = torch.from_numpy(np.array(arr, copy=True)).pin_memory().cuda(non_blocking=True)
-                yield image_id, t, (arr.shape[1], arr.shape[0])
+                yield image_id, t, size
 
 
 def check_supported(args):
@@ -238,8 +248,9 @@ def run_rank(args, world, rank):
     sizes = np.zeros((len(image_ids), 2), np.int32)
     index = {k: i for i, k in enumerate(image_ids)}
     with torch.no_grad():
-        for image_id, img, (w, h) in ImageLoader(images[lo:hi], args.resize, args.max_image_size):
-            if args.auto_contrast:
+        loader = ImageLoader(images[lo:hi], args.resize, args.max_image_size, auto_contrast=args.auto_contrast)
+        for image_id, img, (w, h) in loader:
+            if args.auto_contrast and not loader.auto_contrast_in_loader:
                 img = autocontrast_(img)
             store[image_id] = predict(img.unsqueeze(0))[0]            # uint8 HWC -> fused pre-processing kernel
             sizes[index[image_id]] = (w, h)
@@ -314,12 +325,20 @@ def inference(args, argv=None):
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))))
     try:
-        return run_rank(args, world, rank)
-    finally:
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
+        rows = run_rank(args, world, rank)
+    except BaseException:
+        if world > 1:                                                 # no barrier here: the peers sit in a collective and a
+            import torch.distributed as dist                         # barrier would mismatch it; tear the group down so they
+            try:                                                     # fail fast instead of waiting for the RCCL timeout
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        raise
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return rows
 
 
 def main(argv=None, _spawned_child=False):

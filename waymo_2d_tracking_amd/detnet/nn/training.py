@@ -36,12 +36,34 @@ def match(iou, thresholds, labels, allow_low_quality):
     return idx, out
 
 
-def subsample(labels, num, pos_frac, bg):
+# Per-arch training configuration.  The reference resolves the arch name first against its local configs
+# (detectron2_det/__init__.py:20-27) and falls through to detectron2's model-zoo yaml when there is none - which is the case
+# for the X-152 cascade config: its values are Base-RCNN-FPN.yaml (PRE_NMS_TOPK_TRAIN 2000 per level, POST_NMS_TOPK_TRAIN 1000,
+# RPN batch 256 / 0.5, ROI batch 512 / 0.25) overridden by the zoo file's own `RPN: POST_NMS_TOPK_TRAIN: 2000` (every cascade
+# config of the zoo carries that override; the yaml is not in the reference tree, so this value is recalled, not read).
+TRAIN_CONFIG = {
+    'Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml': dict(pre_nms=2000, post_nms=2000, rpn_batch=256, rpn_pos=0.5,
+                                                                     roi_batch=512, roi_pos=0.25),
+}
+DEFAULT_ARCH = 'Misc/cascade_mask_rcnn_X_152_32x8d_FPN_IN5k_gn_dconv.yaml'
+
+
+def random_choice(candidates, n):
+    """detectron2 subsample_labels: a random subset (torch.randperm on the candidates' device)."""
+    return candidates[torch.randperm(candidates.numel(), device=candidates.device)[:n]]
+
+
+def first_choice(candidates, n):
+    """Deterministic stand-in for the parity tests: the n lowest indices (candidates come out of nonzero() sorted)."""
+    return candidates[:n]
+
+
+def subsample(labels, num, pos_frac, bg, choose=random_choice):
     pos = ((labels != -1) & (labels != bg)).nonzero().flatten()
     neg = (labels == bg).nonzero().flatten()
     n_pos = min(int(num * pos_frac), pos.numel())
     n_neg = min(num - n_pos, neg.numel())
-    return pos[torch.randperm(pos.numel(), device=pos.device)[:n_pos]], neg[torch.randperm(neg.numel(), device=neg.device)[:n_neg]]
+    return choose(pos, n_pos), choose(neg, n_neg)
 
 
 def get_deltas(src, tgt, weights):
@@ -64,9 +86,9 @@ class _ScaleGradient(torch.autograd.Function):
         return g * ctx.scale, None
 
 
-def rpn_losses(rpn, feats, gt_boxes, img_h, img_w, batch_per_image=256, pos_frac=0.5, pre_nms=2000, post_nms=1000):
-    """RPN head on p2..p6 -> (losses, proposals for the ROI heads (detached)).
-    detectron2_det/configs/Base-RCNN-FPN.yaml: PRE_NMS_TOPK_TRAIN 2000 (per level), POST_NMS_TOPK_TRAIN 1000 (per image)."""
+def rpn_losses(rpn, feats, gt_boxes, img_h, img_w, batch_per_image=256, pos_frac=0.5, pre_nms=2000, post_nms=2000,
+               choose=random_choice):
+    """RPN head on p2..p6 -> (losses, proposals for the ROI heads (detached)).  Sizes: TRAIN_CONFIG."""
     logits_l, deltas_l, anchors_l = [], [], []
     boxes_l, scores_l, lvl_l = [], [], []
     for l, f in enumerate(feats):
@@ -83,7 +105,7 @@ def rpn_losses(rpn, feats, gt_boxes, img_h, img_w, batch_per_image=256, pos_frac
     logits, deltas, anchors = torch.cat(logits_l), torch.cat(deltas_l), torch.cat(anchors_l)
     with torch.no_grad():
         idx, lab = match(pairwise_iou(gt_boxes, anchors), [0.3, 0.7], [0, -1, 1], True)
-        pos, neg = subsample(lab, batch_per_image, pos_frac, 0)
+        pos, neg = subsample(lab, batch_per_image, pos_frac, 0, choose)
         boxes = clip_boxes(torch.cat(boxes_l), img_h, img_w)
         scores, lvls = torch.cat(scores_l), torch.cat(lvl_l)
         ok = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
@@ -98,7 +120,8 @@ def rpn_losses(rpn, feats, gt_boxes, img_h, img_w, batch_per_image=256, pos_frac
     return {'loss_rpn_cls': loss_cls, 'loss_rpn_loc': loss_loc}, proposals
 
 
-def roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w, batch_per_image=512, pos_frac=0.25):
+def roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w, batch_per_image=512, pos_frac=0.25,
+               choose=random_choice):
     """CascadeROIHeads._forward_box in training mode."""
     num_classes = model.num_classes
     scales = [1.0 / s for s in (4, 8, 16, 32)]
@@ -107,7 +130,7 @@ def roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w, batc
         boxes = torch.cat((proposals, gt_boxes))                           # proposal_append_gt
         idx, lab = match(pairwise_iou(gt_boxes, boxes), [0.5], [0, 1], False)
         cls = torch.where(lab == 1, gt_classes[idx] if gt_classes.numel() else idx, torch.full_like(idx, num_classes))
-        pos, neg = subsample(cls, batch_per_image, pos_frac, num_classes)
+        pos, neg = subsample(cls, batch_per_image, pos_frac, num_classes, choose)
         keep = torch.cat((pos, neg))
         boxes = boxes[keep]
     for k in range(3):
@@ -134,13 +157,18 @@ def roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w, batc
     return losses
 
 
-def losses(model, image_bgr, gt_boxes, gt_classes):
-    """One image (1,3,H,W) BGR 0..255, gt_boxes (G,4) xyxy pixels, gt_classes (G) in [0, num_classes)."""
+def losses(model, image_bgr, gt_boxes, gt_classes, arch=DEFAULT_ARCH, choose=random_choice, config=None):
+    """One image (1,3,H,W) BGR 0..255, gt_boxes (G,4) xyxy pixels, gt_classes (G) in [0, num_classes).
+    `choose(candidates, n)` is the fg / bg sampler (random like detectron2's; the parity tests inject `first_choice`);
+    `config` overrides TRAIN_CONFIG[arch] (tests shrink the proposal counts for small images)."""
     assert torch.is_grad_enabled()
+    cfg = dict(TRAIN_CONFIG[arch])
+    cfg.update(config or {})
     img_h, img_w = image_bgr.shape[2], image_bgr.shape[3]
     feats = model.backbone(model.preprocess(image_bgr))
-    out, proposals = rpn_losses(model.rpn, feats, gt_boxes, img_h, img_w)
-    out.update(roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w))
+    out, proposals = rpn_losses(model.rpn, feats, gt_boxes, img_h, img_w, cfg['rpn_batch'], cfg['rpn_pos'], cfg['pre_nms'],
+                                cfg['post_nms'], choose)
+    out.update(roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w, cfg['roi_batch'], cfg['roi_pos'], choose))
     return out
 
 
