@@ -290,3 +290,23 @@ def test_image_loader_reports_original_size_and_contrast_precedes_resize(tmp_pat
     exp = np.asarray(ImageOps.autocontrast(Image.fromarray(arr)).resize((ow, oh), Image.BILINEAR))
     assert got.shape == (30, 45, 3) and np.array_equal(got, exp)
     assert not ImageLoader([], resize=None, auto_contrast=True).auto_contrast_in_loader      # GPU autocontrast_ then
+
+
+def test_round_score_halfway_deviation_is_explicit():
+    """ensemble.py:62 `round(bbox[0], 5)` on a numpy float64.  Under the reference's python 3.7 / numpy 1.18 the scalar falls
+    back to float.__round__ (correctly rounded decimal); numpy >= 1.19 (the interpreters available here, and the one the fixtures
+    were generated with) rounds by scale - rint - unscale.  The two differ by one unit of the 5th decimal on many x.xxxxx5
+    inputs.  The host code follows Python's float rounding - this test constructs such scores and pins that choice, so the
+    deviation from the fixtures' numpy is documented rather than hidden behind a tolerance."""
+    from waymo_2d_tracking_amd.detnet import ensemble as E
+    scores = np.array([5e-06 + 0.5, 2.5e-05 + 0.25, 0.300005, 0.123455, 0.99999499999, 0.5], np.float64)
+    out5 = np.zeros((len(scores), 5))
+    out5[:, 0] = scores
+    out5[:, 1:] = [10.9, 20.1, 30.5, 40.99]
+    packed = dict(group_offsets=np.array([0, len(scores)], np.int64), n_groups=1, ncat=1, image_lo=0)
+    rows = E.output_rows(packed, [1], out5, np.array([len(scores)], np.int64), 0.0)
+    assert rows['score'].tolist() == [round(float(v), 5) for v in scores]              # Python's correctly rounded result
+    numpy_way = (np.rint(scores * 1e5) / 1e5)
+    diff = np.abs(rows['score'] - numpy_way)
+    assert (diff > 0).any() and diff.max() < 1.0000001e-5                               # differs, by exactly one unit
+    assert rows['bbox'].tolist() == [[10, 20, 30, 40]] * len(scores)                    # astype(int): truncation

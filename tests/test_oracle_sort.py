@@ -111,3 +111,22 @@ def test_munkres_matches_python_restatement(oracle):
     for shape in ((3, 5), (5, 3), (4, 4)):
         z = np.zeros(shape, np.float32)
         assert np.array_equal(oracle.linear_assignment(z), [[i, i] for i in range(min(shape))])
+
+
+def test_nonfinite_predicted_boxes_match_reference(oracle, golden_dir):
+    """Reference-run fixture G9 (oracle/gen_golden_sort_nonfinite.py): detections whose float32 area overflows drive a track's
+    predicted box to [inf, NaN, ...]; sort.py:258-265 pops it.  The oracle (and the HIP path) drop a track on ANY non-finite
+    coordinate, the reference on NaN only - the generator's docstring shows the two rules cannot be told apart (every reachable
+    non-finite box contains a NaN; an inf injected into the state becomes NaN in filterpy's dense F.x): this test pins the
+    reachable cases, ids and live-track lists call by call."""
+    z = np.load(os.path.join(golden_dir, 'sort_g9_nonfinite.npz'))
+    assert 'popped' in str(z['inf_state_reference_behaviour'])
+    s = oracle.Sort(max_age=2, min_hits=0)
+    for i in range(len(z['in_off']) - 1):
+        dets = z['dets'][z['in_off'][i]:z['in_off'][i + 1]]
+        exp = z['rows'][z['out_off'][i]:z['out_off'][i + 1]]
+        got = s.update(dets, 0.1)
+        assert got.shape == exp.shape, i
+        assert np.array_equal(got[:, 4], exp[:, 4]), i
+        assert np.array_equal(np.isfinite(got), np.isfinite(exp)), i
+        np.testing.assert_allclose(got, exp, rtol=0, atol=BOX_TOL)

@@ -41,7 +41,7 @@ def moving_frames(n_cameras, n_times, height, width, seed, device):
 class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
                  iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta='',
-                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True, n_inflight=1):
+                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True, n_inflight=1, deterministic=False):
         self.dev = torch.device(device)
         # --tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image, folded into the pre-processing kernel
         self.tta_scale, self.tta_hflip = 1.0, False
@@ -52,8 +52,15 @@ class DetectTrackPipeline(object):
                 self.tta_hflip = True
             elif aug != 'orig':
                 raise ValueError('bench supports --tta orig / xS / hflip, got %r' % aug)
-        torch.backends.cudnn.benchmark = True      # the reference's --cudnn-benchmark: let MIOpen pick its fastest conv
-        enable_gemm_tuning()                       # ... and TunableOp its fastest library GEMM per 1x1-conv shape
+        if deterministic:
+            # run-to-run bit-identical library kernels (tests: graph replay == eager launches): MIOpen's deterministic solvers,
+            # no find-mode search (its winner may accumulate split-K partial sums with atomics), library-default GEMM picks
+            torch.backends.cudnn.benchmark = False
+            torch.backends.cudnn.deterministic = True
+            torch.cuda.tunable.enable(False)
+        else:
+            torch.backends.cudnn.benchmark = True  # the reference's --cudnn-benchmark: let MIOpen pick its fastest conv
+            enable_gemm_tuning()                   # ... and TunableOp its fastest library GEMM per 1x1-conv shape
         self.nc, self.fpc, self.h, self.w = n_cameras, frames_per_camera, height, width
         self.model = model if model is not None else Detectron2Det(seed=seed).to(self.dev).eval()
         self.n_frames = n_cameras * frames_per_camera
