@@ -79,6 +79,9 @@ def init_dist(args):
     torch.cuda.set_device(local if dist_on else 0)
     if dist_on:
         import torch.distributed as dist
+        if 'RANK' not in os.environ:                 # WT_FORCE_DIST=1 without a launcher: a one-rank group on this GPU
+            from waymo_2d_tracking_amd import launcher
+            os.environ.update(launcher.rank_environments(1, launcher.free_port(), {})[0])
         if torch.cuda.device_count() <= local:
             raise SystemExit('bench.py: rank %d needs GPU %d but only %d visible' % (rank, local, torch.cuda.device_count()))
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))

@@ -237,3 +237,137 @@ def forward(model, image_bgr, dtype=torch.float32, return_intermediates=False, p
     if return_intermediates:
         return result, dict(feats=feats, proposals=props, stage_out=stage_out, boxes=boxes, scores=scores)
     return result
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# Training losses (row a23 / config 5): what detectron2 computes when the reference calls Detectron2Det.loss
+# (/root/reference/detnet/nn/detectron2_det/__init__.py:144-186 -> GeneralizedRCNN.forward in training mode), restated on the CPU
+# ops above so that autograd yields float64 reference gradients.  Independent of waymo_2d_tracking_amd/detnet/nn/training.py.
+# The fg / bg subsampling is random in detectron2 (subsample_labels); the parity tests make BOTH sides take the lowest indices.
+
+def _iou_matrix(gt, boxes):
+    """(G, N) pairwise IoU, detectron2.structures.pairwise_iou (0 where the boxes do not intersect)."""
+    area_g = (gt[:, 2] - gt[:, 0]) * (gt[:, 3] - gt[:, 1])
+    area_b = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    lt = torch.max(gt[:, None, :2], boxes[None, :, :2])
+    rb = torch.min(gt[:, None, 2:], boxes[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_g[:, None] + area_b[None, :] - inter
+    return torch.where(inter > 0, inter / union, torch.zeros_like(inter))
+
+
+def _matcher(iou, thresholds, labels, low_quality):
+    """detectron2.modeling.matcher.Matcher.__call__: per box the best gt and a label from the threshold bands."""
+    vals, idx = iou.max(dim=0)
+    lab = torch.full_like(idx, 1)
+    bounds = [-float('inf')] + list(thresholds) + [float('inf')]
+    for l, lo, hi in zip(labels, bounds[:-1], bounds[1:]):
+        lab[(vals >= lo) & (vals < hi)] = l
+    if low_quality:                                   # set_low_quality_matches_: boxes that realise a gt's best IoU
+        best = iou.max(dim=1, keepdim=True)[0]
+        lab[(iou == best).any(dim=0)] = 1
+    return idx, lab
+
+
+def _take_first(labels, num, frac, bg):
+    pos = torch.nonzero((labels != -1) & (labels != bg)).flatten()
+    neg = torch.nonzero(labels == bg).flatten()
+    n_pos = min(int(num * frac), pos.numel())
+    n_neg = min(num - n_pos, neg.numel())
+    return pos[:n_pos], neg[:n_neg]
+
+
+def _deltas(src, tgt, weights):
+    """Box2BoxTransform.get_deltas."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    scx, scy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+    tcx, tcy = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+    return torch.stack((weights[0] * (tcx - scx) / sw, weights[1] * (tcy - scy) / sh, weights[2] * torch.log(tw / sw),
+                        weights[3] * torch.log(th / sh)), dim=1)
+
+
+class _GradScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def losses(model, image_bgr, gt_boxes, gt_classes, dtype=torch.float64, rpn_batch=256, rpn_pos=0.5, pre_nms=2000, post_nms=2000,
+           roi_batch=512, roi_pos=0.25, proposals=None, return_intermediates=False):
+    """The 8 detectron2 losses of the Cascade R-CNN for one image, differentiable (call .backward() on their sum).
+    RPN: Matcher([0.3, 0.7], [0, -1, 1], low quality on), 256 anchors at 0.5 positive, BCE sum / 256 and L1 sum / 256
+    (smooth_l1 beta 0).  Proposals: per-level top `pre_nms`, decode, clip, drop empty, per-level NMS 0.7, `post_nms` best.
+    ROI heads: gt boxes appended, stage-1 Matcher([0.5]) + 512 at 0.25 foreground, stages 2 / 3 rematch at 0.6 / 0.7 without
+    resampling on the previous stage's decoded boxes (clipped, empty removed), pooled features with gradient scale 1/3,
+    mean cross-entropy and class-agnostic L1 on the foreground rows / number of rows."""
+    gt_boxes = gt_boxes.to(dtype)
+    num_classes = model.num_classes
+    img_h, img_w = image_bgr.shape[2], image_bgr.shape[3]
+    x = ((image_bgr.to(dtype) - model.pixel_mean.to(dtype)) / model.pixel_std.to(dtype))
+    ph, pw = (32 - img_h % 32) % 32, (32 - img_w % 32) % 32
+    if ph or pw:
+        x = F.pad(x, (0, pw, 0, ph))
+    feats = backbone(model.backbone, x)
+    r = model.rpn
+    logits_l, deltas_l, anchors_l, boxes_l, scores_l, lvl_l = [], [], [], [], [], []
+    for l, f in enumerate(feats):
+        t = convbn(r.conv, f, relu=True)
+        lg = conv1x1(r.objectness, t).permute(0, 2, 3, 1).reshape(-1)
+        dl = conv1x1(r.deltas, t).permute(0, 2, 3, 1).reshape(-1, 4)
+        an = r.anchors(l, f.shape[2], f.shape[3], f.device).to(dtype)
+        logits_l.append(lg); deltas_l.append(dl); anchors_l.append(an)
+        with torch.no_grad():
+            k = min(pre_nms, lg.numel())
+            top, idx = torch.topk(lg, k, sorted=True)
+            boxes_l.append(apply_deltas(dl[idx], an[idx], (1.0, 1.0, 1.0, 1.0))); scores_l.append(top)
+            lvl_l.append(torch.full((k,), l, dtype=torch.int32))
+    logits, deltas, anchors = torch.cat(logits_l), torch.cat(deltas_l), torch.cat(anchors_l)
+    out = {}
+    with torch.no_grad():
+        idx, lab = _matcher(_iou_matrix(gt_boxes, anchors), [0.3, 0.7], [0, -1, 1], True)
+        pos, neg = _take_first(lab, rpn_batch, rpn_pos, 0)
+        tgt_d = _deltas(anchors[pos], gt_boxes[idx[pos]], (1.0, 1.0, 1.0, 1.0))
+        if proposals is None:
+            b = clip_boxes(torch.cat(boxes_l), img_h, img_w)
+            s, lv = torch.cat(scores_l), torch.cat(lvl_l)
+            ok = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+            b, s, lv = b[ok], s[ok], lv[ok]
+            proposals = b[batched_nms(b, s, lv, r.thr)[:post_nms]]
+        else:
+            proposals = proposals.to(dtype)
+    sel = torch.cat((pos, neg))
+    target = torch.cat((torch.ones(len(pos), dtype=dtype), torch.zeros(len(neg), dtype=dtype)))
+    out['loss_rpn_cls'] = F.binary_cross_entropy_with_logits(logits[sel], target, reduction='sum') / rpn_batch
+    out['loss_rpn_loc'] = (deltas[pos] - tgt_d).abs().sum() / rpn_batch
+    inter = dict(proposals=proposals, rpn_pos=pos, rpn_neg=neg)
+    with torch.no_grad():
+        boxes = torch.cat((proposals, gt_boxes))
+        idx, lab = _matcher(_iou_matrix(gt_boxes, boxes), [0.5], [0, 1], False)
+        cls = torch.where(lab == 1, gt_classes[idx], torch.full_like(idx, num_classes))
+        pos, neg = _take_first(cls, roi_batch, roi_pos, num_classes)
+        boxes = boxes[torch.cat((pos, neg))]
+    scales = [1.0 / s for s in (4, 8, 16, 32)]
+    for k in range(3):
+        with torch.no_grad():
+            if k > 0:
+                boxes = clip_boxes(boxes, img_h, img_w)
+                boxes = boxes[((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)]
+            idx, lab = _matcher(_iou_matrix(gt_boxes, boxes), [(0.5, 0.6, 0.7)[k]], [0, 1], False)
+            cls = torch.where(lab == 1, gt_classes[idx], torch.full_like(idx, num_classes))
+            tgt_boxes = gt_boxes[idx]
+        inter['stage%d_boxes' % k] = boxes
+        inter['stage%d_classes' % k] = cls
+        pooled = _GradScale.apply(roi_pool_fpn(feats[:4], boxes, scales), 1.0 / 3)
+        lg, dl = box_head(model.heads[k], pooled)
+        fg = torch.nonzero(cls < num_classes).flatten()
+        out['loss_cls_stage%d' % k] = F.cross_entropy(lg, cls, reduction='mean')
+        out['loss_box_reg_stage%d' % k] = (dl[fg] - _deltas(boxes[fg], tgt_boxes[fg], model.CASCADE_WEIGHTS[k])).abs().sum() / max(len(cls), 1)
+        boxes = apply_deltas(dl.detach(), boxes, model.CASCADE_WEIGHTS[k])
+    return (out, inter) if return_intermediates else out

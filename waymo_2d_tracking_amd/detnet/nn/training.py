@@ -157,17 +157,19 @@ def roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w, batc
     return losses
 
 
-def losses(model, image_bgr, gt_boxes, gt_classes, arch=DEFAULT_ARCH, choose=random_choice, config=None):
+def losses(model, image_bgr, gt_boxes, gt_classes, arch=DEFAULT_ARCH, choose=random_choice, config=None, proposals=None):
     """One image (1,3,H,W) BGR 0..255, gt_boxes (G,4) xyxy pixels, gt_classes (G) in [0, num_classes).
     `choose(candidates, n)` is the fg / bg sampler (random like detectron2's; the parity tests inject `first_choice`);
-    `config` overrides TRAIN_CONFIG[arch] (tests shrink the proposal counts for small images)."""
+    `config` overrides TRAIN_CONFIG[arch] (tests shrink the proposal counts for small images); `proposals` (R, 4) replaces
+    the RPN's own proposals as input of the ROI heads (detectron2's precomputed-proposals mode; parity tests)."""
     assert torch.is_grad_enabled()
     cfg = dict(TRAIN_CONFIG[arch])
     cfg.update(config or {})
     img_h, img_w = image_bgr.shape[2], image_bgr.shape[3]
     feats = model.backbone(model.preprocess(image_bgr))
-    out, proposals = rpn_losses(model.rpn, feats, gt_boxes, img_h, img_w, cfg['rpn_batch'], cfg['rpn_pos'], cfg['pre_nms'],
-                                cfg['post_nms'], choose)
+    out, own = rpn_losses(model.rpn, feats, gt_boxes, img_h, img_w, cfg['rpn_batch'], cfg['rpn_pos'], cfg['pre_nms'],
+                          cfg['post_nms'], choose)
+    proposals = own if proposals is None else proposals
     out.update(roi_losses(model, feats, proposals, gt_boxes, gt_classes, img_h, img_w, cfg['roi_batch'], cfg['roi_pos'], choose))
     return out
 
