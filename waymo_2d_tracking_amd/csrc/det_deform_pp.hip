@@ -52,6 +52,9 @@ constexpr size_t SMEM = (size_t)BW_F * 4 + 4 * (size_t)PATCH_F * 4 + 2 * (size_t
 #else
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #endif
+// slot boundary: the "memory" clobber keeps LLVM's IR passes from sinking the LDS loads to their uses behind the MFMA burst, the
+// sched_barrier keeps the machine scheduler from moving anything across
+#define PP_SLOT() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifndef PP_DMA_K
 #define PP_DMA_K 5
 #endif
@@ -521,13 +524,26 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
 #endif
         // the slot boundaries are also scheduling barriers: hipcc otherwise moves the next tap's blend (and its LDS waits)
         // up into the MFMA slot, which serialises the wave on LDS latency and defeats the two-team phase structure
-        if (k == 7) PP_BARRIER();                                 // table of the next tile written -> readable (M(7) reads entry 0)
+        if (k == 7) PP_BARRIER();                                 // table of the next tile written -> readable (entry 0 is read below)
+        constexpr int kn = (k + 1) % 9;
+#ifndef PP_LATE_READS
+        // round 3: the LDS requests of the NEXT tap (corners -> cv, weights -> b[(k+1) & 1]) and the table entry of the tap after it
+        // are issued BEFORE this tap's MFMA burst and the slot boundaries are scheduling barriers.  hipcc used to sink them behind
+        // the burst and start the next blend right after them: ~200 cycles of LDS latency exposed per tap (SQ_WAIT_ANY 32 % of the
+        // wave cycles).  cv is dead once blend() has produced a[], so no extra registers are live across the burst.
+        issue_reads(kn, b[(k + 1) & 1], kn >= RW);
+        read_entry((kn + 1) % 9);
+        PP_SLOT();
+#endif
         // ---- M(k) ----
         if constexpr (k < RW) mfma_tap(wres[k]);
         else mfma_tap(b[k & 1]);
-        constexpr int kn = (k + 1) % 9;
+#ifndef PP_LATE_READS
+        PP_SLOT();
+#else
         issue_reads(kn, b[(k + 1) & 1], kn >= RW);
         read_entry((kn + 1) % 9);
+#endif
         if (k == 6) PP_BARRIER();                                 // every wave has read entry 8 -> the table may be rewritten in G(7)
     };
 
