@@ -31,7 +31,7 @@ UNITS = {
     'det_roialign.hip': [],
     'det_nms.hip': [],
     'det_deform.hip': [],
-    'det_deform_pp.hip': [],
+    'det_deform_pp.hip': ['-fno-slp-vectorize'],      # explicit 2-vectors in the blend; the SLP pass hoists its tree to the LDS loads
     'det_gconv.hip': [],
     'det_gemm.hip': ['-munsafe-fp-atomics'],
     'det_gemm_lt.hip': [],

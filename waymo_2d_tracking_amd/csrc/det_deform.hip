@@ -739,7 +739,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout
 }  // namespace
 
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
-                        const float* bias, int relu, int batch, int h, int w, int c, hipStream_t stream, float* y, const void* table);
+                        const float* bias, int relu, int batch, int h, int w, int c, int cg, hipStream_t stream, float* y,
+                        const void* table);
 int wd_grouped_conv3x3_c8_launch(const float* x, const float* packed_weight, const float* scale, const float* bias, int relu,
                                  int batch, int h, int w, int c, hipStream_t stream, float* y);
 
@@ -748,7 +749,7 @@ static int deform_variant(int cg, int stride, int pad, bool has_offset, const ch
     const bool fits = has_offset && stride == 1 && pad == 1;
     if (mode && strcmp(mode, "none") == 0) return 0;
     if (mode && strcmp(mode, "all") == 0) return (fits && (cg == 16 || cg == 32 || cg == 64)) ? 1 : 0;
-    if (fits && cg == 32 && !(mode && strcmp(mode, "lds") == 0)) return 3;      // persistent kernel (falls back to 2 with a mask)
+    if (fits && (cg == 32 || cg == 16) && !(mode && strcmp(mode, "lds") == 0)) return 3;      // persistent kernel (falls back to 2 with a mask)
     if (fits && (cg == 16 || cg == 32)) return 2;
     if (fits && cg == 64) return 1;
     return 0;
@@ -760,7 +761,7 @@ const char* wd_deform_conv3x3_variant(int c_in, int groups, int stride, int pad,
     if (groups <= 0 || c_in % groups) return "invalid";
     const int cg = c_in / groups;
     switch (deform_variant(cg, stride, pad, has_offset != 0, getenv("WD_DEFORM_PATCH"))) {
-        case 3: return "deform_conv3x3_pp_kernel<32>";
+        case 3: return cg == 16 ? "deform_conv3x3_pp_kernel<16>" : "deform_conv3x3_pp_kernel<32>";
         case 2: return cg == 16 ? "deform_conv3x3_lds_kernel<16>" : "deform_conv3x3_lds_kernel<32>";
         case 1: return cg == 16 ? "deform_conv3x3_patch_kernel<16>" : cg == 32 ? "deform_conv3x3_patch_kernel<32>" : "deform_conv3x3_patch_kernel<64>";
         default: break;
@@ -841,7 +842,7 @@ int wd_deform_conv3x3_tab_f32(const float* x, const float* offset, const float* 
     if (variant == 3 && (mask || far_offsets)) variant = 2;  // the ping-pong kernel has no modulation mask; with many samples leaving
                                                              // the 14x14 patch its per-lane far path loses to the per-tile one
     if (variant == 3)
-        return wd_deform_pp_launch(x, offset, packed_weight, scale, bias, relu, batch, h, w, c_in, stream, y, table);
+        return wd_deform_pp_launch(x, offset, packed_weight, scale, bias, relu, batch, h, w, c_in, cg, stream, y, table);
     if (variant == 2) {
         const long nwg_p = ntiles * (c_in / PCH);
         dim3 gridp((unsigned)((nwg_p + 7) / 8 * 8));
