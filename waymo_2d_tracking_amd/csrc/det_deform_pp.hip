@@ -479,6 +479,24 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         prep(k == 8 ? base_nxt : base_cur);                       // the next tap lives in the next tile's patch when k == 8
         if constexpr (kn < RW) issue_reads(kn, b[0], false, k == 8 ? nxt.tn : cur.tn);
         else issue_reads(kn, b[(k + 1) & 1], true, k == 8 ? nxt.tn : cur.tn);
+        // side jobs: the compiler waits for ALL vector-memory operations right before the next tap's corner requests (the corner
+        // registers may be the target of global loads), so stores and DMA requests are issued right behind this tap's and have a
+        // whole tap to complete
+#ifndef PP_NO_SIDE
+#ifndef PP_NO_EPI
+        if (k == 0 && it > 0) epilogue();
+#endif
+        if (k == 1) {                                             // next tile of this team: patch + table on their way for 6 taps
+            have_next = it + 1 < n_items;
+            if (have_next) {
+                nxt = tile_xy(it + 1);
+#ifndef PP_NO_DMA
+                issue_patch(nxt, base_nxt);
+                issue_table(nxt, tab_nxt);
+#endif
+            }
+        }
+#endif
         if (k == 7) {
             // the tile's only barrier.  Before it: every read of THIS tile's patch and table has been issued (tap 8's corners just
             // above, entry 8 in G(6)), so the DMA of tap 1 of the next tile may overwrite them; own DMA pieces (and zero-fill
@@ -495,23 +513,6 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         // the corner registers pass through an (empty) volatile asm behind the burst: the next tap's blend depends on its outputs, so
         // neither LLVM's IR passes nor the DAG scheduler can move that blend (and the wait for its loads) in front of the MFMAs
         pin_corners();
-        // side jobs behind the pin: the compiler waits for ALL vector-memory operations there (the corner registers may come from
-        // global memory), so stores and DMA requests are issued right after it and have a whole tap to complete
-#ifndef PP_NO_SIDE
-#ifndef PP_NO_EPI
-        if (k == 0 && it > 0) epilogue();
-#endif
-        if (k == 1) {                                             // next tile of this team: patch + table on their way for 5 taps
-            have_next = it + 1 < n_items;
-            if (have_next) {
-                nxt = tile_xy(it + 1);
-#ifndef PP_NO_DMA
-                issue_patch(nxt, base_nxt);
-                issue_table(nxt, tab_nxt);
-#endif
-            }
-        }
-#endif
     };
 
     __syncthreads();
