@@ -360,6 +360,31 @@ def cpu_baseline_e2e(pipe, track, height=448, width=640):
                 full_res_equivalent=1.0 / (t_det * ratio + t_sort))
 
 
+def cpu_baseline_train(det, height=160, width=224):
+    """One training step (forward, the 8 losses, backward) of the CPU restatement (oracle/detector_ref.losses, float32, same
+    parameters) on the host cores at 224x160 - the 886x1280 crop has 31.6x the pixels; `full_res_equivalent` scales the measured
+    step by that ratio (the ROI heads do not scale with the image, so this flatters the CPU).  A port, not the reference: detectron2
+    cannot run here."""
+    import copy
+    import torch
+    from oracle import detector_ref as R
+    from waymo_2d_tracking_amd.detnet.nn import training
+    cpu = copy.deepcopy(det.model).cpu()
+    training.set_trainable(cpu)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (1, 3, height, width), generator=g).float()
+    gt = torch.tensor([[20., 30., 120., 150.], [100., 40., 215., 155.], [5., 5., 60., 60.], [130., 8., 200., 70.]])
+    cls = torch.tensor([0, 1, 3, 0])
+    t0 = time.perf_counter()
+    out = R.losses(cpu, img, gt, cls, torch.float32)
+    sum(out.values()).backward()
+    dt = time.perf_counter() - t0
+    ratio = (886 * 1280) / float(height * width)
+    return dict(value=1.0 / dt, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='1 training step (fwd + 8 losses + bwd) at %dx%d through oracle/detector_ref.losses (PyTorch CPU fp32): %.1f s; '
+                       '886x1280 has %.1fx the pixels' % (width, height, dt, ratio), full_res_equivalent=1.0 / (dt * ratio))
+
+
 def main():
     args = parse_args()
     launch_if_needed(args)         # no GPU call before this line
@@ -376,6 +401,9 @@ def main():
     elif args.stage == 'train':
         from waymo_2d_tracking_amd import bench_e2e
         res, steps, warmup = bench_e2e.run_train(args, world, rank, timed_steps)
+        det = res.pop('model')
+        if rank == 0 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline_train(det)
         metric = 'training images/sec (fwd+bwd+step), Cascade R-CNN X152 dconv, 886x1280 crops'
     else:
         from waymo_2d_tracking_amd import bench_e2e

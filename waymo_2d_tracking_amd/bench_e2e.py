@@ -322,12 +322,53 @@ def collation_report(pipe, world, rank):
     return rep
 
 
+def deform_offset_sweep(stds=(0.0, 0.5, 1.0, 2.0), c=1024, h=80, w=120, launches=30):
+    """The roofline kernel (res4 deformable conv through the pipeline's entry points: sampling table from the offset conv's gather
+    launch, persistent kernel) at several offset spreads, iid N(0, std^2) px per pixel and tap - outside the timed region, HIP events
+    on the launch stream.  The random-init bench model's own layers have a spread of 0.1 - 0.2 px; trained DCN offsets are
+    routinely >= 1 px, which is why the bench line reports all of them instead of the best case only."""
+    import ctypes as C
+    from . import _lib
+    from .detnet.nn import ops
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = torch.randn((1, c, h, w), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    pw = ops.deform_pack_weight((torch.randn((c, c // 32, 3, 3), generator=g) * 0.05).to(dev), 32)
+    sc, bi = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    lib = _lib.lib()
+    lib.wd_deform_table_bytes.restype = C.c_size_t
+    table = torch.empty(int(lib.wd_deform_table_bytes(C.c_int(1), C.c_int(h), C.c_int(w))), dtype=torch.uint8, device=dev)
+    flops = 2.0 * c * (c // 32) * 9 * h * w
+    out = {}
+    for std in stds:
+        off = (torch.randn((1, 18, h, w), generator=g) * std).to(dev)
+        partial = torch.zeros((h * w, 176), device=dev)                     # the offsets as the centre-tap partial sums of the offset conv
+        partial[:, 72:90] = off.permute(0, 2, 3, 1).reshape(-1, 18)
+        offs = torch.empty((1, 18, h, w), device=dev).contiguous(memory_format=torch.channels_last)
+        _lib.check(lib.wd_deform_offsets_table_f32(C.c_void_p(partial.data_ptr()), C.c_int(176), None, C.c_int(1), C.c_int(h), C.c_int(w),
+                                                   C.c_void_p(offs.data_ptr()), C.c_void_p(table.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'wd_deform_offsets_table_f32')
+        run = lambda: ops.deform_conv3x3(x, offs, pw, 32, 1, 1, sc, bi, True, table=table)
+        for _ in range(5):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / launches * 1e3
+        share = float((off.abs() > 2.0).reshape(1, 9, 2, h, w).any(dim=2).float().mean().item())
+        out['%.1f px' % std] = dict(avg_us=us, tflops=flops / us / 1e6, frac=flops / us / 1e6 / 157.3, samples_outside_patch=share)
+    return out
+
+
 def _pmc_traffic(tag):
-    """HBM bytes per launch of the roofline kernel from the committed PMC pass (profiles/r01_e2e_pmc_traffic.json,
+    """HBM bytes per launch of the roofline kernel from the committed PMC pass (profiles/r0N_e2e_pmc_traffic.json,
     collected with tools/pmc_traffic.sh - counters cannot be read from inside the timed run); None if not recorded."""
     import json
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-    for fname in ('r02_e2e_pmc_traffic.json', 'r01_e2e_pmc_traffic.json'):
+    for fname in ('r03_e2e_pmc_traffic.json', 'r02_e2e_pmc_traffic.json', 'r01_e2e_pmc_traffic.json'):
         try:
             rec = json.load(open(os.path.join(root, fname)))
         except (OSError, ValueError):
@@ -387,6 +428,14 @@ def run(args, world, rank, timed_steps):
                         flops_per_launch=flops,
                         all_shapes={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, tflops=v[2] / (v[1] / v[0] * 1e-3) / 1e12)
                                     for k, v in by_shape.items()})
+        dsh = {k: v for k, v in by_shape.items() if 'no offsets' not in k}
+        tot_f = sum(v[2] * v[0] for v in dsh.values())
+        tot_s = sum(v[1] for v in dsh.values()) * 1e-3
+        roofline['all_deformable_launches'] = dict(launches=sum(v[0] for v in dsh.values()), tflops=tot_f / tot_s / 1e12,
+                                                  frac=tot_f / tot_s / 1e12 / 157.3)
+        roofline['offset_spread_of_bench_model'] = 'std 0.10 - 0.21 px per layer (random-init offset convs, tools/offset_stats.py)'
+        if rank == 0:
+            roofline['by_offset_spread'] = deform_offset_sweep()
     res = dict(value=frames * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, dtype='f32',
                workload='Cascade R-CNN X152-32x8d-FPN dconv (random-init, fp32, batch 1%s) on synthetic 1920x1280x3 frames'
                         ' -> top-100 detections/frame -> %s; %d cameras x %d frames per step per GPU'
@@ -443,9 +492,38 @@ def run_train(args, world, rank, timed_steps):
 
     steps = args.steps or 3
     warmup = args.warmup if args.warmup is not None else 1
-    dt, ev_ms = timed_steps(world, step, steps, warmup)
+    from .detnet.nn import ops
+    state = {'n': 0}
+
+    def timed():
+        if state['n'] == warmup:
+            ops.EVENT_LOG = []                                   # HIP events around the col2im launches of the timed steps only
+        state['n'] += 1
+        step()
+
+    dt, ev_ms = timed_steps(world, timed, steps, warmup)
+    log, ops.EVENT_LOG = ops.EVENT_LOG or [], None
+    torch.cuda.synchronize()
+    # roofline of the dominant hand-written BACKWARD kernel: deformable col2im (dx as a gather over the inverted sampling table +
+    # doffset), HBM-bound: algorithmic bytes per launch / mean launch duration of the most expensive shape
+    by = {}
+    for tag, nbytes, e0, e1 in log:
+        if tag.startswith('deform_col2im'):
+            d = by.setdefault(tag, [0, 0.0, nbytes])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+    roofline = None
+    if by:
+        tag = max(by, key=lambda k: by[k][1])
+        cnt, ms, nbytes = by[tag]
+        ach = nbytes / (ms / cnt * 1e-3) / 1e9
+        roofline = dict(bound='hbm', kernel=tag, achieved=ach, peak=8000.0, unit='GB/s', frac=ach / 8000.0, traffic=None, launches=cnt,
+                        avg_us=ms / cnt * 1e3, bytes_per_launch=nbytes,
+                        all_shapes={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, gbs=v[2] / (v[1] / v[0] * 1e-3) / 1e9) for k, v in by.items()})
     res = dict(value=world * steps / dt, unit='images/s', ms_per_step=1e3 * dt / steps, dtype='f32',
                workload='Cascade R-CNN X152-32x8d-FPN dconv training step (fwd+bwd+SGD), 886x1280 crop, batch 1/GPU, '
                         '30 synthetic gt boxes, FREEZE_AT 2, FrozenBN, %s' % ('DDP x%d over RCCL' % world if world > 1 else 'single GPU'),
+               roofline=roofline,
                extra=dict(loss=float(last['loss']), trainable_params=sum(p.numel() for p in params)))
+    res['model'] = det
     return res, steps, warmup

@@ -122,7 +122,6 @@ class Bottleneck(nn.Module):
         super().__init__()
         width = cout                      # 32x8d: bottleneck width == stage output channels (job.log:363-376)
         self.stride, self.deform = stride, deform
-        self._far_offsets, self._far_v = None, -1         # per-layer kernel hint, recalibrated when the offset conv's weights change
         self.shortcut = Conv1x1(cin, cout, gen) if cin != cout else None
         self.conv1 = Conv1x1(cin, width, gen)
         if deform:
@@ -168,19 +167,16 @@ class Bottleneck(nn.Module):
             # stride 1: library GEMM over the input pixels (162 columns) + tap shift-add kernel instead of a direct
             # 18-channel implicit GEMM (MIOpen pads N 18 -> 32 and adds the bias in a second pass)
             table = None
-            if self.stride == 1 and self.conv2_weight.shape[1] == 32:
-                # 32 channels per group (res4): the persistent kernel's sampling table is built once per layer inside the offset
-                # conv's gather launch instead of in each of the kernel's 32 channel-group workgroups
+            if self.stride == 1 and self.conv2_weight.shape[1] in (16, 32):
+                # 16 / 32 channels per group (res3 / res4): the persistent kernel's sampling table is built once per layer inside the
+                # offset conv's gather launch and DMA'd per tile by the kernel; samples that leave the kernel's 14x14 patch are
+                # fetched from global memory by their own lane one tap ahead (round 3: 2-px offset spread 93 us vs 144 us for the
+                # per-tile fallback kernel, so the round-2 per-layer calibration + host sync is gone)
                 offset, table = self.offset_conv(out, deform_table=True)
             else:
                 offset = self.offset_conv(out) if self.stride == 1 else self.conv2_offset(out)
-            wv = self.conv2_offset.weight._version
-            if self.stride == 1 and self._far_v != wv and not torch.cuda.is_current_stream_capturing():
-                # calibrated once per layer on the first frame it sees (one host sync, outside stream capture): layers whose
-                # learned offsets leave the persistent kernel's patch often take the per-tile fallback kernel
-                self._far_offsets, self._far_v = ops.far_offset_share(offset) > ops.FAR_OFFSET_SHARE, wv
             out = ops.deform_conv3x3(out, offset, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
-                                     self.conv2_bias, relu=True, far_offsets=bool(self._far_offsets), table=table)
+                                     self.conv2_bias, relu=True, table=table)
         else:
             out = ops.deform_conv3x3(out, None, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
                                      self.conv2_bias, relu=True)

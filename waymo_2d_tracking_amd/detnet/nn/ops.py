@@ -165,7 +165,8 @@ def deform_conv3x3(x, offset, packed_weight, groups, stride=1, pad=1, scale=None
 
 
 FAR_OFFSET_PX = 2.0          # halo of the persistent kernel's 14x14 input patch
-FAR_OFFSET_SHARE = 0.2       # share of samples beyond it from which the per-tile fallback kernel wins
+FAR_OFFSET_SHARE = 0.2       # round 2: share of samples beyond it from which the per-tile fallback kernel won; since round 3 the
+                             # persistent kernel is faster at every spread measured (tools/deform_r3_bench.py) - diagnostics only
 
 
 def far_offset_share(offset):
@@ -447,9 +448,20 @@ def deform_col2im(dcol, x, offset, stride=1, pad=1, groups=1):
     n, c, h, w = x.shape
     dx = torch.zeros_like(x, memory_format=torch.channels_last)
     doff = torch.zeros_like(offset, memory_format=torch.channels_last)
+    log = EVENT_LOG
+    if log is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.lib().wd_deform_col2im_f32(_p(dcol), _p(x), _p(offset), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
                                                C.c_int(groups), C.c_int(stride), C.c_int(pad), _p(dx), _p(doff), _stream()),
                'wd_deform_col2im_f32')
+    if log is not None:
+        e1.record()
+        ho, wo = offset.shape[2], offset.shape[3]
+        # algorithmic HBM bytes: the column gradients once (P x 9 x C floats), the offsets in, dx and doffset out, x for doffset
+        nbytes = 4.0 * (n * ho * wo * 9 * c + 2 * n * ho * wo * 18 + 2 * n * h * w * c)
+        log.append(('deform_col2im (dx gather + doffset): C=%d %dx%d s%d' % (c, ho, wo, stride), nbytes, e0, e1))
     return dx, doff
 
 
