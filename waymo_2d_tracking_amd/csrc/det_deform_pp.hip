@@ -27,6 +27,7 @@
 //   * four independent accumulator chains; D = W x samples (weights are the A operand): a lane ends up with 4 consecutive output
 //     channels of its pixel -> the epilogue (FrozenBN affine + ReLU) writes 16 bytes per lane and 16-channel tile.
 // LDS (32 channels per group): 24 576 (weights of 6 taps) + 4 x 25 216 (patches) + 4 x 9 216 (tables) = 162 304 bytes.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "../../include/waymodet.h"
@@ -592,6 +593,8 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
     int nsplit = n_cu / items;
+    static const int nsplit_env = getenv("WD_PP_NSPLIT") ? atoi(getenv("WD_PP_NSPLIT")) : 0;    // experiments: fewer workgroups per item
+    if (nsplit_env > 0 && nsplit_env < nsplit) nsplit = nsplit_env;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > (ntiles + 1) / 2) nsplit = (ntiles + 1) / 2;       // at least two tiles (one per team) per workgroup
     if (nsplit < 1) nsplit = 1;
