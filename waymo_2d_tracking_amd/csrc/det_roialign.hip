@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_kernel(Levels lv, int n_leve
                                                            const float* __restrict__ rois, int n_rois, int P,
                                                            int min_level, int canonical_level, float canonical_size,
                                                            float* __restrict__ out, const int* __restrict__ only_flagged) {
-    for (int r = blockIdx.x; r < n_rois; r += gridDim.x) {
-    if (only_flagged && !only_flagged[r]) continue;       // already done by the separable kernel
+    const int r = blockIdx.x;
+    if (only_flagged && !only_flagged[r]) return;         // already done by the separable kernel
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const float* roi = rois + 5 * (size_t)r;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_kernel(Levels lv, int n_leve
     const float scale = lv.scale[li];
     if (b < 0 || b >= batch) {                       // malformed roi: zeros
         for (int i = threadIdx.x; i < P * P * C; i += 256) out[(size_t)r * P * P * C + i] = 0.f;
-        continue;
+        return;
     }
     feat += (size_t)b * H * W * C;
     // ROIAlign forward, aligned=True
@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_kernel(Levels lv, int n_leve
             }
         }
     }
-    }   // ROIs of this workgroup
 }
 
 constexpr int kMaxFoot = 64;      // footprint rows / columns handled by the separable kernel (larger: direct kernel)
@@ -478,8 +477,7 @@ extern "C" int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* hei
         else
             hipLaunchKernelGGL(roi_pool_sep_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
                                channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out, flags);
-        // (64 workgroups walk the flag list: flagged ROIs are rare - whole-image boxes - and 1000 mostly idle workgroups cost 4.8 us)
-        hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)(n_rois < 64 ? n_rois : 64)), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
+        hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
                            channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out,
                            (const int*)flags);
     } else {
