@@ -145,6 +145,10 @@ def test_linear_assignment_vs_oracle(oracle):
         cost = -np.round(rng.uniform(0, 1, (n, m)), 2).astype(np.float32)
         cost[rng.uniform(size=(n, m)) < [0.0, 0.5, 0.9][trial % 3]] = 0
         assert np.array_equal(linear_assignment(cost), oracle.linear_assignment(cost)), (n, m)
+    for n, m in ((90, 300), (300, 90), (100, 384), (128, 383), (60, 250), (129, 200), (100, 385), (100, 400)):      # wide register variants + LDS fallback
+        cost = -np.round(rng.uniform(0, 1, (n, m)), 2).astype(np.float32)
+        cost[rng.uniform(size=(n, m)) < 0.9] = 0
+        assert np.array_equal(linear_assignment(cost), oracle.linear_assignment(cost)), (n, m)
     for shape in ((3, 5), (5, 3), (1, 1), (70, 65)):
         z = np.zeros(shape, np.float32)
         assert np.array_equal(linear_assignment(z), [[i, i] for i in range(min(shape))])

@@ -419,63 +419,128 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
             }
             if (fr < 0) {
                 WT_TICK(8)
-                // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
-                float mn = __builtin_inff();
-                bool any_r = false, any_c = false;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) {
-                    if (w >= W) continue;
-                    const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
-                    const unsigned long long valid = (c1 == 64) ? ~0ull : ((1ull << c1) - 1ull);
-                    any_c = any_c || ((~cc[w] & valid) != 0ull);
-                }
-#pragma unroll
-                for (int j = 0; j < RM; ++j) {
-                    if (j >= R) continue;
-                    const int r = j * kWave + lane;
-                    const bool unc = (r < n) && !((rcov[j] >> lane) & 1ull);
-                    any_r = any_r || (__ballot(unc) != 0ull);
-                    if (unc) {
-#pragma unroll
+                if constexpr (WM <= 2) {
+                // (<= 128 columns: ROW-parallel - lane = row, serial over the row's columns; faster for the small LDS-resident matrices of
+                //  the batch stages: 31.7 k vs 19.5 k frames/s on the 1-segment track stage)
+                    // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
+                    float mn = __builtin_inff();
+                    bool any_r = false, any_c = false;
+    #pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        if (w >= W) continue;
+                        const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                        const unsigned long long valid = (c1 == 64) ? ~0ull : ((1ull << c1) - 1ull);
+                        any_c = any_c || ((~cc[w] & valid) != 0ull);
+                    }
+    #pragma unroll
+                    for (int j = 0; j < RM; ++j) {
+                        if (j >= R) continue;
+                        const int r = j * kWave + lane;
+                        const bool unc = (r < n) && !((rcov[j] >> lane) & 1ull);
+                        any_r = any_r || (__ballot(unc) != 0ull);
+                        if (unc) {
+    #pragma unroll
+                            for (int w = 0; w < WM; ++w) {
+                                if (w >= W) continue;
+                                unsigned long long todo = ~cc[w];
+                                const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                                if (c1 < 64) todo &= (1ull << c1) - 1ull;
+                                while (todo) {
+                                    const int c = __builtin_ctzll(todo);
+                                    todo &= todo - 1ull;
+                                    const float v = C[r * ld + 64 * w + c];
+                                    mn = (v < mn) ? v : mn;
+                                }
+                            }
+                        }
+                    }
+                    mn = wave_min_f(mn);
+                    if (any_r && any_c) {
+    #pragma unroll
+                        for (int j = 0; j < RM; ++j) {
+                            if (j >= R) continue;
+                            const int r = j * kWave + lane;
+                            if (r < n) {
+                                const bool rcv = (rcov[j] >> lane) & 1ull;
+    #pragma unroll
+                                for (int w = 0; w < WM; ++w) {
+                                    if (w >= W) continue;
+                                    const unsigned long long cw = cc[w];
+                                    const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                                    unsigned long long zz = 0ull;
+                                    for (int c = 0; c < c1; ++c) {
+                                        float v = C[r * ld + 64 * w + c];
+                                        const bool ccov = (cw >> c) & 1ull;
+                                        if (rcv || !ccov) {
+                                            if (rcv) v = v + mn;
+                                            if (!ccov) v = v - mn;
+                                            C[r * ld + 64 * w + c] = v;
+                                        }
+                                        zz |= (v == 0.f) ? (1ull << c) : 0ull;
+                                    }
+                                    z[j][w] = zz;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns.
+                    // Round 3: COLUMN-parallel (lane = column, rows visited one after the other): the cost matrix of the online pipeline
+                    // (100 x 300, 120 KB) lives in global memory, where the old row-per-lane walk touched 64 cache lines per load
+                    // instruction - 90 % of the tracker's cycles on the end-to-end workload.  Elementwise the same float operations
+                    // in the same order (v + mn first, then - mn), min is exact: identical matrices, identical zero bitmaps.
+                    float mn = __builtin_inff();
+                    bool any_r = false, any_c = false;
+    #pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        if (w >= W) continue;
+                        const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                        const unsigned long long valid = (c1 == 64) ? ~0ull : ((1ull << c1) - 1ull);
+                        any_c = any_c || ((~cc[w] & valid) != 0ull);
+                    }
+                    for (int r = 0; r < n; ++r) {
+                        unsigned long long rc = 0ull;
+    #pragma unroll
+                        for (int j = 0; j < RM; ++j) if (j == (r >> 6)) rc = rcov[j];
+                        if ((rc >> (r & 63)) & 1ull) continue;                      // covered row (wave-uniform)
+                        any_r = true;
+    #pragma unroll
                         for (int w = 0; w < WM; ++w) {
                             if (w >= W) continue;
-                            unsigned long long todo = ~cc[w];
-                            const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
-                            if (c1 < 64) todo &= (1ull << c1) - 1ull;
-                            while (todo) {
-                                const int c = __builtin_ctzll(todo);
-                                todo &= todo - 1ull;
-                                const float v = C[r * ld + 64 * w + c];
+                            const int c = 64 * w + lane;
+                            if (c < m && !((cc[w] >> lane) & 1ull)) {
+                                const float v = C[r * ld + c];
                                 mn = (v < mn) ? v : mn;
                             }
                         }
                     }
-                }
-                mn = wave_min_f(mn);
-                if (any_r && any_c) {
-#pragma unroll
-                    for (int j = 0; j < RM; ++j) {
-                        if (j >= R) continue;
-                        const int r = j * kWave + lane;
-                        if (r < n) {
-                            const bool rcv = (rcov[j] >> lane) & 1ull;
-#pragma unroll
+                    mn = wave_min_f(mn);
+                    if (any_r && any_c) {
+                        for (int r = 0; r < n; ++r) {
+                            unsigned long long rc = 0ull;
+    #pragma unroll
+                            for (int j = 0; j < RM; ++j) if (j == (r >> 6)) rc = rcov[j];
+                            const bool rcv = (rc >> (r & 63)) & 1ull;                 // wave-uniform
+    #pragma unroll
                             for (int w = 0; w < WM; ++w) {
                                 if (w >= W) continue;
-                                const unsigned long long cw = cc[w];
-                                const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
-                                unsigned long long zz = 0ull;
-                                for (int c = 0; c < c1; ++c) {
-                                    float v = C[r * ld + 64 * w + c];
-                                    const bool ccov = (cw >> c) & 1ull;
+                                const int c = 64 * w + lane;
+                                const bool valid = c < m;
+                                const bool ccov = (cc[w] >> lane) & 1ull;
+                                float v = 1.f;
+                                if (valid) {
+                                    v = C[r * ld + c];
                                     if (rcv || !ccov) {
                                         if (rcv) v = v + mn;
                                         if (!ccov) v = v - mn;
-                                        C[r * ld + 64 * w + c] = v;
+                                        C[r * ld + c] = v;
                                     }
-                                    zz |= (v == 0.f) ? (1ull << c) : 0ull;
                                 }
-                                z[j][w] = zz;
+                                const unsigned long long zz = __ballot(valid && v == 0.f);
+                                if (lane == (r & 63)) {
+    #pragma unroll
+                                    for (int j = 0; j < RM; ++j) if (j == (r >> 6)) z[j][w] = zz;
+                                }
                             }
                         }
                     }
@@ -515,6 +580,10 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
 template <class CostPtr>
 __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L) {
     if (n <= 128 && m <= 128) return munkres_wave_reg<2, 2>(C, n, m, ld, L);
+    // round 3: the online detect -> track pipeline keeps (max_age + 2) x 100 track slots per class: up to 100 x 400 problems when the
+    // detector's boxes do not persist.  Same code with wider column bitmaps (zero bitmaps 12 VGPR pairs per lane, covers scalar).
+    // (<2, 7> and <2, 4> + <2, 7> trip a hipcc 7.2 backend error "V_CMP_NE_U32_e32 0, $src_shared_base"; <2, 6> compiles)
+    if (n <= 128 && m <= 384) return munkres_wave_reg<2, 6>(C, n, m, ld, L);
     const int lane = threadIdx.x & 63;
     const int W = (m + 63) >> 6;
     for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;

@@ -17,7 +17,9 @@ using namespace wtdev;
 
 namespace {
 
-constexpr int kLdsCostFloats = 8192;          // 32 KiB of cost matrix in LDS per wave
+constexpr int kLdsCostFloats = 8192;          // 32 KiB of cost matrix in LDS per wave (thousands of trackers: 4 workgroups per CU)
+constexpr int kLdsCostFloatsFew = 36864;      // 144 KiB when every tracker can own a CU anyway (<= 256 trackers: the online pipeline's 5-20):
+                                              // a 100 x 300 cost matrix then stays in LDS instead of global memory
 constexpr size_t kLdsMunkresMax = 120 * 1024;   // stars / primes / zero bitmaps (dynamic LDS, raised limit)  // stars/primes/covers
 
 // Persistent part of a set of trackers: survives between the chunks of the streaming entry points
@@ -434,7 +436,7 @@ __global__ void totals_kernel(const long long* totals, const int* err, int64_t* 
 }
 
 int pick_caps(int64_t max_frame_dets, const wt_track_params* p, int* cap, int* capN, int* lds_cost, bool* cost_g,
-              size_t* lds_bytes) {
+              size_t* lds_bytes, int64_t n_streams) {
     if (!p || p->n_classes < 1 || !p->iou_threshold || !p->score_threshold || p->max_age < 0) {
         wt::set_error("bad wt_track_params");
         return WT_ERR_INVALID;
@@ -445,10 +447,16 @@ int pick_caps(int64_t max_frame_dets, const wt_track_params* p, int* cap, int* c
     *capN = (int)n;
     *cap = (int)c;
     const int64_t full = (int64_t)(*capN) * ((*cap) | 1);
-    *lds_cost = (int)(full < kLdsCostFloats ? full : kLdsCostFloats);
-    *cost_g = full > kLdsCostFloats;
     const size_t mk = wtdev::munkres_lds_bytes(*capN, *cap);
     if (mk > kLdsMunkresMax) { wt::set_error("frame with %lld detections exceeds the LDS budget of the assignment kernel", (long long)n); return WT_ERR_CAPACITY; }
+    int64_t budget = kLdsCostFloats;
+    if (n_streams > 0 && n_streams * (int64_t)p->n_classes <= 256) {           // few trackers: what the CU's 160 KiB leave next to the bitmaps
+        const int64_t room = ((int64_t)160 * 1024 - 512 - (int64_t)mk) / 4;
+        budget = room < kLdsCostFloatsFew ? room : kLdsCostFloatsFew;
+        if (budget < kLdsCostFloats) budget = kLdsCostFloats;
+    }
+    *lds_cost = (int)(full < budget ? full : budget);
+    *cost_g = full > budget;
     *lds_bytes = wt::align_up((size_t)(*lds_cost) * sizeof(float), 16) + mk;
     return WT_OK;
 }
@@ -513,7 +521,7 @@ extern "C" {
 size_t wt_track_streams_workspace(int64_t n_dets, int64_t n_frames, int32_t n_streams, int64_t max_frame_dets,
                                   const wt_track_params* params) {
     int cap, capN, lds_cost; bool cost_g; size_t lds;
-    if (pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds) != WT_OK) return 0;
+    if (pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds, n_streams) != WT_OK) return 0;
     return carve_ws(nullptr, n_dets, n_frames, n_streams, params->n_classes, cap, capN, cost_g).bytes +
            carve_state(nullptr, n_streams, params->n_classes, cap).bytes + 256;
 }
@@ -530,7 +538,7 @@ int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const
     WT_TRY(wt::ensure_device());
     hipStream_t stream = (hipStream_t)stream_;
     int cap, capN, lds_cost; bool cost_g; size_t lds;
-    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds, n_streams));
     const int C = params->n_classes;
     if (n_streams <= 0 || n_frames <= 0) {
         WT_HIP(hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), stream));
@@ -552,7 +560,7 @@ int wt_track_streams_dev(int64_t n_dets, const double* x, const double* y, const
 /* ---- streaming form: the trackers persist in `state` between chunks of frames ---- */
 size_t wt_track_state_bytes(int32_t n_streams, int64_t max_frame_dets, const wt_track_params* params) {
     int cap, capN, lds_cost; bool cost_g; size_t lds;
-    if (n_streams <= 0 || pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds) != WT_OK) return 0;
+    if (n_streams <= 0 || pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds, n_streams) != WT_OK) return 0;
     return carve_state(nullptr, n_streams, params->n_classes, cap).bytes + 256;
 }
 
@@ -560,7 +568,7 @@ int wt_track_state_init_dev(void* state, size_t state_bytes, int32_t n_streams, 
                             const wt_track_params* params, void* stream_) {
     WT_TRY(wt::ensure_device());
     int cap, capN, lds_cost; bool cost_g; size_t lds;
-    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds, n_streams));
     if (n_streams <= 0) { wt::set_error("n_streams must be positive"); return WT_ERR_INVALID; }
     const int C = params->n_classes;
     State st = carve_state(align256(state), n_streams, C, cap);
@@ -578,7 +586,7 @@ int wt_track_state_init_dev(void* state, size_t state_bytes, int32_t n_streams, 
 size_t wt_track_chunk_workspace(int64_t n_dets, int64_t n_frames, int32_t n_streams, int64_t max_frame_dets,
                                 const wt_track_params* params) {
     int cap, capN, lds_cost; bool cost_g; size_t lds;
-    if (pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds) != WT_OK) return 0;
+    if (pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds, n_streams) != WT_OK) return 0;
     return carve_ws(nullptr, n_dets, n_frames, n_streams, params->n_classes, cap, capN, cost_g).bytes + 256;
 }
 
@@ -595,7 +603,7 @@ int wt_track_chunk_dev(void* state, size_t state_bytes,
     WT_TRY(wt::ensure_device());
     hipStream_t stream = (hipStream_t)stream_;
     int cap, capN, lds_cost; bool cost_g; size_t lds;
-    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds, n_streams));
     const int C = params->n_classes;
     if (n_streams <= 0) { wt::set_error("n_streams must be positive"); return WT_ERR_INVALID; }
     if (n_frames <= 0) {
@@ -625,7 +633,7 @@ int wt_track_global_ids_dev(const void* state, size_t state_bytes, int32_t n_str
     WT_TRY(wt::ensure_device());
     hipStream_t stream = (hipStream_t)stream_;
     int cap, capN, lds_cost; bool cost_g; size_t lds;
-    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds));
+    WT_TRY(pick_caps(max_frame_dets, params, &cap, &capN, &lds_cost, &cost_g, &lds, n_streams));
     if (n_streams <= 0 || !stream_birth_prefix) { wt::set_error("bad arguments"); return WT_ERR_INVALID; }
     State st = carve_state(align256(const_cast<void*>(state)), n_streams, params->n_classes, cap);
     if (!state || state_bytes < st.bytes + 256) { wt::set_error("tracker state too small"); return WT_ERR_CAPACITY; }
