@@ -340,11 +340,54 @@ __global__ __launch_bounds__(256) void roi_pool_row_kernel(Levels lv, int n_leve
     const int r_hi = low_index(y_last, H) + 1 < H ? low_index(y_last, H) + 1 : H - 1;
     const int q_hi = low_index(x_last, W) + 1 < W ? low_index(x_last, W) + 1 : W - 1;
     const int nrows = r_hi - r_lo + 1, ncols = q_hi - q_lo + 1;
-    if (nrows > kMaxFoot || ncols > kMaxFoot || nrows < 1 || ncols < 1) {       // rare: the direct kernel does the ROI
-        if (lane == 0) fallback_flags[r] = 1;
+    if (lane == 0) fallback_flags[r] = 0;
+    if (nrows > kMaxFoot || ncols > kMaxFoot || nrows < 1 || ncols < 1) {
+        // rare (whole-image boxes: footprint beyond the 64 x 64 weight tables): this wave does its bin row by direct bilinear
+        // sampling, sample by sample (round 3: the separate fallback launch - 1000 mostly idle workgroups, 4.8 - 7.6 us per call -
+        // is gone).  Same sample positions, weights and accumulation order as roi_pool_fpn_kernel.
+        for (int cb = 0; cb < C; cb += 256) {
+            const int c = cb + lane * 4;
+            const bool cok = c < C;
+            const float* __restrict__ fc = feat + (cok ? c : 0);
+            float4 acc[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int iy = 0; iy < gh; ++iy) {
+                float yy = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+                const bool yok = !(yy < -1.0f || yy > (float)H);
+                if (yy <= 0) yy = 0;
+                int yl = (int)yy, yh;
+                if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+                const float ly = yy - (float)yl, hy = 1.f - ly;
+                const float* __restrict__ r0 = fc + (size_t)yl * W * C;
+                const float* __restrict__ r1 = fc + (size_t)yh * W * C;
+                for (int ix = 0; ix < gw; ++ix) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        float x = rsw + (float)j * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                        const bool ok = yok && !(x < -1.0f || x > (float)W);
+                        if (x <= 0) x = 0;
+                        int xl = (int)x, xh;
+                        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                        if (!ok) { xl = 0; xh = 0; }
+                        const float lx = ok ? x - (float)xl : 0.f, hx = ok ? 1.f - lx : 0.f;
+                        const float4 v1 = *reinterpret_cast<const float4*>(r0 + (size_t)xl * C), v2 = *reinterpret_cast<const float4*>(r0 + (size_t)xh * C);
+                        const float4 v3 = *reinterpret_cast<const float4*>(r1 + (size_t)xl * C), v4 = *reinterpret_cast<const float4*>(r1 + (size_t)xh * C);
+                        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+                        acc[j].x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x; acc[j].y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+                        acc[j].z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z; acc[j].w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+                    }
+                }
+            }
+            if (cok) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    *reinterpret_cast<float4*>(orow + (size_t)j * C + c) =
+                        make_float4(acc[j].x / count, acc[j].y / count, acc[j].z / count, acc[j].w / count);
+            }
+        }
         return;
     }
-    if (lane == 0) fallback_flags[r] = 0;
     for (int i = lane; i < 8 * kMaxFoot; i += 64) (&tab[0][0])[i] = 0.f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -470,16 +513,18 @@ extern "C" int wd_roi_pool_fpn_f32(const float* const* feats, const int32_t* hei
                                n_rois, min_level, canonical_level, canonical_size, order);
         }
         const char* mode = getenv("WD_ROI_KERNEL");             // experiments: "sep" = one workgroup per ROI
-        if ((channels & 3) == 0 && ((uintptr_t)out & 15) == 0 && !(mode && strcmp(mode, "sep") == 0))
+        const bool row_path = (channels & 3) == 0 && ((uintptr_t)out & 15) == 0 && !(mode && strcmp(mode, "sep") == 0);
+        if (row_path)
             hipLaunchKernelGGL(roi_pool_row_kernel, dim3((unsigned)(order ? (((n_rois * 7 + 3) / 4 + 7) / 8 * 8) : (n_rois * 7 + 3) / 4)),
                                dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels, batch, rois, n_rois, min_level,
                                canonical_level, canonical_size, out, flags, (const int*)order);
         else
             hipLaunchKernelGGL(roi_pool_sep_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
                                channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out, flags);
-        hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
-                           channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out,
-                           (const int*)flags);
+        if (!row_path)      // the one-workgroup-per-ROI kernel still flags its large ROIs for the direct kernel
+            hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
+                               channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out,
+                               (const int*)flags);
     } else {
         hipLaunchKernelGGL(roi_pool_fpn_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels,
                            channels, batch, rois, n_rois, pooled, min_level, canonical_level, canonical_size, out,
