@@ -37,6 +37,7 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 namespace pp {
 constexpr int PS = 14;                 // patch side: 8 + 2 (3x3 footprint) + 2 * 2 (halo for the learned offsets)
@@ -66,6 +67,15 @@ template <int CG> constexpr size_t smem_bytes() {
 // slot boundary: the "memory" clobber keeps LLVM's IR passes from sinking the LDS loads to their uses behind the MFMA burst, the
 // sched_barrier keeps the machine scheduler from moving anything across
 #define PP_SLOT() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// EXPLORATORY (bf16x3 mode, never the benchmarked path): v = hi + lo + O(2^-16 |v|) with hi, lo in bfloat16
+__device__ __forceinline__ void pp_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = (__bf16)v[i];
+        lo[i] = (__bf16)(v[i] - (float)hi[i]);
+    }
+}
 
 // fragment row r (0..15) of M tile m -> pixel (y, x) of the 8x8 tile (see header: even columns on rows {0-3, 12-15})
 __device__ __forceinline__ int pp_row_pixel(int r, int m) {
@@ -176,11 +186,15 @@ __global__ __launch_bounds__(256) void deform_table_kernel(const float* __restri
     }
 }
 
-template <int CG>
+// BF3 (exploratory, 32 channels per group only): the implicit GEMM as three bf16 MFMAs per 16-channel tile and tap (hi.hi + hi.lo + lo.hi of a
+// 2-way bfloat16 split of weights and samples, f32 accumulation) on the bf16 matrix pipe - 6 x ~17 cycles instead of 16 x 32, and that pipe
+// overlaps with VALU.  About 16 mantissa bits per operand: NOT fp32; measured and reported as an `extra` only (tools/bf16x3_experiment.py).
+template <int CG, bool BF3 = false>
 __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     const float* __restrict__ x, const float* __restrict__ wfrag, const float* __restrict__ scale, const float* __restrict__ bias,
     int relu, int batch, int H, int W, int C, int Cout, int nsplit, float* __restrict__ y, const uint4* __restrict__ table) {
     static_assert(CG == 32 || CG == 16, "32 channels per group, or two groups of 16 per item");
+    static_assert(!BF3 || CG == 32, "the bf16x3 experiment exists for 32 channels per group only");
     constexpr int NQ = CG == 32 ? 4 : 2;                     // float4 weight fragments per lane and tap
     constexpr int RW = pp::RW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -293,7 +307,28 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     {
         // wfrag (pack_weight_kernel's fragment copy): CG 32: [group][tap][lane][16]; CG 16: [group][tap][lane][4], an item = groups 2g, 2g+1
         // -> bw[tap - RW][q][lane][4]
-        if (CG == 32) {
+        if constexpr (CG == 32 && BF3) {
+            // per (tap, lane): the 16 weights [tile][k] -> 4 x 16 bytes [tile 0 hi | tile 0 lo | tile 1 hi | tile 1 lo] (8 bf16 each)
+            const float* src = wfrag + (size_t)g * 9 * 64 * 16;
+            auto split_tap = [&](int k, int ln, f32x4 (&dst)[4]) {
+                float v0[8], v1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v0[i] = src[(k * 64 + ln) * 16 + i]; v1[i] = src[(k * 64 + ln) * 16 + 8 + i]; }
+                bf16x8 h0, l0, h1, l1;
+                pp_split8(v0, h0, l0); pp_split8(v1, h1, l1);
+                dst[0] = __builtin_bit_cast(f32x4, h0); dst[1] = __builtin_bit_cast(f32x4, l0);
+                dst[2] = __builtin_bit_cast(f32x4, h1); dst[3] = __builtin_bit_cast(f32x4, l1);
+            };
+            for (int e = tid; e < (9 - RW) * 64; e += 512) {
+                const int ln = e & 63, k = e >> 6;
+                f32x4 d[4];
+                split_tap(k + RW, ln, d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(bw + ((k * 4 + j) * 64 + ln) * 4) = d[j];
+            }
+#pragma unroll
+            for (int k = 0; k < RW; ++k) split_tap(k, lane, wres[k]);
+        } else if constexpr (CG == 32) {
             const f32x4* src = reinterpret_cast<const f32x4*>(wfrag + (size_t)g * 9 * 64 * 16);
             for (int e = tid; e < (9 - RW) * 64 * 4; e += 512) {
                 const int j = e & 3, ln = (e >> 2) & 63, k = e >> 8;
@@ -440,7 +475,18 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         return;
 #endif
 #define PP_MM(ch, t, wa, av) acc[2 * (ch) + (t)] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, av, acc[2 * (ch) + (t)], 0, 0, 0);
-        if constexpr (CG == 32) {
+        if constexpr (CG == 32 && BF3) {
+            bf16x8 xh, xl;
+            pp_split8(a, xh, xl);
+            const bf16x8 w0h = __builtin_bit_cast(bf16x8, bb[0]), w0l = __builtin_bit_cast(bf16x8, bb[1]);
+            const bf16x8 w1h = __builtin_bit_cast(bf16x8, bb[2]), w1l = __builtin_bit_cast(bf16x8, bb[3]);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0h, xh, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h, xh, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0h, xl, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h, xl, acc[3], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0l, xh, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l, xh, acc[1], 0, 0, 0);
+        } else if constexpr (CG == 32) {
             // k-step kk: channels 8 kq + kk of the lane's pixel; output tiles 0 / 1 = channels 0-15 / 16-31 of the group
             PP_MM(0, 0, bb[0].x, a[0]) PP_MM(0, 1, bb[2].x, a[0]) PP_MM(1, 0, bb[0].y, a[1]) PP_MM(1, 1, bb[2].y, a[1])
             PP_MM(0, 0, bb[0].z, a[2]) PP_MM(0, 1, bb[2].z, a[2]) PP_MM(1, 0, bb[0].w, a[3]) PP_MM(1, 1, bb[2].w, a[3])
@@ -599,7 +645,17 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
     if (nsplit > (ntiles + 1) / 2) nsplit = (ntiles + 1) / 2;       // at least two tiles (one per team) per workgroup
     if (nsplit < 1) nsplit = 1;
     const float* wfrag = packed_weight + (size_t)c * cg * 9;       // lane-major fragment copy (pack_weight_kernel)
-    if (cg == 32)
+    static const bool bf3 = getenv("WD_DEFORM_BF16X3") && getenv("WD_DEFORM_BF16X3")[0] == '1';     // EXPERIMENT: not fp32 (see the kernel's header)
+    if (cg == 32 && bf3) {
+        static bool attr3 = false;
+        if (!attr3) {
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<32, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<32>()));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((deform_conv3x3_pp_kernel<32, true>), dim3((unsigned)(items * nsplit)), dim3(512), pp::smem_bytes<32>(), stream, x,
+                           wfrag, scale, bias, relu, batch, h, w, c, c, nsplit, y, (const uint4*)table);
+    } else if (cg == 32)
         hipLaunchKernelGGL(deform_conv3x3_pp_kernel<32>, dim3((unsigned)(items * nsplit)), dim3(512), pp::smem_bytes<32>(), stream, x,
                            wfrag, scale, bias, relu, batch, h, w, c, c, nsplit, y, (const uint4*)table);
     else
