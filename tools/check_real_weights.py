@@ -44,7 +44,7 @@ def main():
         m = Detectron2Det(pretrained='coco')                    # raises FileNotFoundError with the expected path when absent
         model_path = os.path.join(out_dir, 'model.pth')
         detnn.save(m, model_path)
-    argv = ['-i', args.images, '--model', model_path, '--export', os.path.join(out_dir, 'det.json'), '--cudnn-benchmark']
+    argv = ['-i', args.images, '--model', model_path, '--export', os.path.join(out_dir, 'det.json')]
     if args.tta:
         argv += ['--tta', args.tta]
     if args.annotations:
