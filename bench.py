@@ -222,7 +222,7 @@ def stage_track(args, world, rank):
         res['verified'] = dict(ok=bool(births == ref['n_births'] and np.array_equal(out['object_id'], ref['object_id'])
                                        and np.array_equal(out['frame'], ref['frame']) and np.array_equal(out['bbox'], ref['bbox'])),
                                rows=rows, rows_ref=int(len(ref['frame'])), against='oracle/sort_oracle.c on the same detections')
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:       # the CPU baseline is timed at N = 1 only
         res['cpu_baseline'] = cpu_baseline_track(ithr, sthr)
     return res, steps, warmup
 
@@ -308,7 +308,7 @@ def stage_ensemble(args, world, rank):
             for g in range(len(off) - 1))
         res['verified'] = dict(ok=ok, groups=int(len(off) - 1), rows=int(counts.sum()),
                                against='oracle/softnms_oracle.c on the same groups, bit-exact')
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:       # the CPU baseline is timed at N = 1 only
         from oracle import oracle as O
         O.build()
         n_img = max(1, min(args.images, 60))
@@ -402,7 +402,7 @@ def main():
         from waymo_2d_tracking_amd import bench_e2e
         res, steps, warmup = bench_e2e.run_train(args, world, rank, timed_steps)
         det = res.pop('model')
-        if rank == 0 and not args.no_cpu_baseline:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:       # the CPU baseline is timed at N = 1 only
             res['cpu_baseline'] = cpu_baseline_train(det)
         metric = 'training images/sec (fwd+bwd+step), Cascade R-CNN X152 dconv, 886x1280 crops'
     else:
@@ -416,7 +416,7 @@ def main():
             O.build()
             res['verified'] = dict(bench_e2e.check_against(pipe, O.track_streams),
                                    against='oracle/sort_oracle.c replay of the slots the timed steps filled')
-        if rank == 0 and not args.no_cpu_baseline:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:       # the CPU baseline is timed at N = 1 only
             res['cpu_baseline'] = cpu_baseline_e2e(pipe, args.stage == 'e2e')
         metric = 'end-to-end frames/sec (detect+SORT) on 1920x1280 Waymo frames' if args.stage == 'e2e' else \
             'detector frames/sec on 1920x1280 Waymo frames'
