@@ -407,3 +407,31 @@ def test_deform_table_prepass_equals_in_kernel_table(H, W, batch, off_std):
     ya = O.deform_conv3x3(x, off_a, packed, 32, 1, 1)
     yb = O.deform_conv3x3(x, off_b, packed, 32, 1, 1, table=table)
     assert torch.equal(ya, yb)
+
+
+def test_bf16x3_experiment_mode_stays_close_to_fp32(tmp_path):
+    """WD_DEFORM_BF16X3=1 (exploratory, never benchmarked: 2-way bfloat16 split of weights and samples on the bf16 matrix pipe) in a
+    fresh process (the switch is read once): the result stays within 1e-4 of the float64 restatement relative to the output's
+    scale - the mode is a measured experiment, and this keeps it from rotting."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, numpy as np
+sys.path.insert(0, %r)
+from oracle import detops_ref as R
+from waymo_2d_tracking_amd.detnet.nn import ops
+g = torch.Generator().manual_seed(5)
+C, H, W = 128, 19, 26
+x = torch.randn((1, C, H, W), generator=g)
+off = torch.randn((1, 18, H, W), generator=g) * 1.5
+w = torch.randn((C, 32, 3, 3), generator=g) / (3 * 32 ** 0.5)
+exp = R.deform_conv3x3(x, off, w, 4, 1, 1)
+cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+got = ops.deform_conv3x3(cl(x), cl(off), ops.deform_pack_weight(w.cuda(), 4), 4, 1, 1).cpu().double()
+err = float((got - exp).abs().max() / exp.pow(2).mean().sqrt())
+print('ERR', err)
+assert err < 1e-4, err
+assert err > 1e-7        # it really is the split path (the f32 kernel agrees to ~1e-7)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, WD_DEFORM_BF16X3='1'), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
