@@ -374,7 +374,9 @@ def _pmc_traffic(tag):
         except (OSError, ValueError):
             continue
         for name, v in rec.items():
-            if tag.startswith(name):
+            # the profiler prints all template arguments ("..._pp_kernel<32, false>"), the bench tag only the first ("..._pp_kernel<32>: ...")
+            base, targ = name.split('<')[0], name.split('<')[1].split(',')[0].rstrip('>') if '<' in name else ''
+            if tag.startswith(name) or (tag.startswith(base + '<' + targ) and targ):
                 return v.get('traffic_bytes_per_launch')
     return None
 
