@@ -120,10 +120,14 @@ int wd_deform_conv3x3_f32(const float* x, const float* offset, const float* mask
 int wd_deform_conv3x3_hint_f32(const float* x, const float* offset, const float* mask, const float* packed_weight,
                                const float* scale, const float* bias, int relu, int batch, int h, int w, int c_in,
                                int c_out, int groups, int stride, int pad, int far_offsets, float* y, void* stream);
-/* The persistent kernel's sampling table (one entry per pixel and tap: 4 corner slots + bilinear fractions) depends on the offsets
- * only, not on the channel group: wd_deform_offsets_table_f32 builds it once per layer inside the offset conv's epilogue launch
- * (it replaces wd_tap_shift_add_f32 there: same offsets, same arithmetic), wd_deform_conv3x3_tab_f32 consumes it (table may be
- * NULL = the kernel builds its own entries; ignored by the other kernel variants).  Same batch / h / w on both calls. */
+/* The persistent kernel (stride 1, 16 or 32 channels per group) reads a per-layer sampling table: one 16-byte entry per (pixel, tap) - the 4
+ * corner slots inside the kernel's 14x14 input patch + the bilinear fractions, or, for a sample whose corners leave the patch, its image
+ * coordinates (the kernel then fetches that sample from global memory itself) - followed by one flag per 8x8 tile.  The table depends on the
+ * offsets only, not on the channel group: wd_deform_offsets_table_f32 builds it inside the offset conv's epilogue launch (it replaces
+ * wd_tap_shift_add_f32 there: same offsets, same arithmetic), wd_deform_conv3x3_tab_f32 consumes it (table may be NULL = the library builds
+ * it from `offset` into an internal scratch buffer with one extra launch; ignored by the other kernel variants).  Same batch / h / w on both
+ * calls.  far_offsets != 0 (wd_deform_conv3x3_hint_f32) still selects the round-1 per-tile kernel; since round 3 the persistent kernel is
+ * faster at every offset spread measured, so callers normally pass 0. */
 size_t wd_deform_table_bytes(int batch, int h, int w);
 int wd_deform_offsets_table_f32(const float* partial, int ld, const float* bias, int batch, int h, int w, float* offsets,
                                 void* table, void* stream);
