@@ -739,7 +739,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout
 }  // namespace
 
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
-                        const float* bias, int relu, int batch, int h, int w, int c, int cg, hipStream_t stream, float* y,
+                        const float* bias, int relu, int batch, int h, int w, int c, int cg, int stride, hipStream_t stream, float* y,
                         const void* table);
 int wd_grouped_conv3x3_c8_launch(const float* x, const float* packed_weight, const float* scale, const float* bias, int relu,
                                  int batch, int h, int w, int c, hipStream_t stream, float* y);
@@ -748,6 +748,9 @@ int wd_grouped_conv3x3_c8_launch(const float* x, const float* packed_weight, con
 static int deform_variant(int cg, int stride, int pad, bool has_offset, const char* mode) {
     const bool fits = has_offset && stride == 1 && pad == 1;
     if (mode && strcmp(mode, "none") == 0) return 0;
+    // stride 2, 16 / 32 channels per group (round 3): the persistent kernel with its patch over the middle of the 17 x 17 footprint and
+    // the far path for the rest: res3 322 -> ~125 us, res4 160 -> ~90 us
+    if (has_offset && stride == 2 && pad == 1 && (cg == 32 || cg == 16) && !(mode && strcmp(mode, "lds") == 0)) return 3;
     if (mode && strcmp(mode, "all") == 0) return (fits && (cg == 16 || cg == 32 || cg == 64)) ? 1 : 0;
     if (fits && (cg == 32 || cg == 16) && !(mode && strcmp(mode, "lds") == 0)) return 3;      // persistent kernel (falls back to 2 with a mask)
     if (fits && (cg == 16 || cg == 32)) return 2;
@@ -839,10 +842,11 @@ int wd_deform_conv3x3_tab_f32(const float* x, const float* offset, const float* 
             return wd_grouped_conv3x3_c8_launch(x, packed_weight, scale, bias, relu, batch, h, w, c_in, stream, y);
     }
     int variant = deform_variant(cg, stride, pad, offset != nullptr, mode);
-    if (variant == 3 && (mask || far_offsets)) variant = 2;  // the ping-pong kernel has no modulation mask; with many samples leaving
+    if (variant == 3 && stride != 1 && mask) variant = 0;    // stride 2 + modulation mask: the gather kernel
+    if (variant == 3 && stride == 1 && (mask || far_offsets)) variant = 2;  // the ping-pong kernel has no modulation mask; with many samples leaving
                                                              // the 14x14 patch its per-lane far path loses to the per-tile one
     if (variant == 3)
-        return wd_deform_pp_launch(x, offset, packed_weight, scale, bias, relu, batch, h, w, c_in, cg, stream, y, table);
+        return wd_deform_pp_launch(x, offset, packed_weight, scale, bias, relu, batch, h, w, c_in, cg, stride, stream, y, table);
     if (variant == 2) {
         const long nwg_p = ntiles * (c_in / PCH);
         dim3 gridp((unsigned)((nwg_p + 7) / 8 * 8));

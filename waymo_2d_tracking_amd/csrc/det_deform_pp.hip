@@ -94,8 +94,16 @@ __device__ __forceinline__ int pp_slot(int p, int q) { return (p << 3) + (q ^ ((
 //          the image) points at the zero pixel
 //   z, w : the bilinear fractions lh, lw
 //   far  : y = FAR_Y, x = (row + 32768) | (column + 32768) << 16 of the sample's upper-left corner in IMAGE coordinates
-__device__ __forceinline__ uint4 pp_make_entry(bool pixel_in_image, float t_fy, float t_fx, float2 ov, int ty, int tx, int H, int W) {
-    const float py0 = (float)(ty * 8 - 3), px0 = (float)(tx * 8 - 3);
+// Stride S (1 or 2): the patch origin is image pixel (S * 8 ty - org, S * 8 tx - org) with org = 3 for stride 1 (2-pixel halo around the
+// 10 x 10 footprint of undeformed taps) and org = -1 for stride 2: there the undeformed footprint is 17 x 17, the 14 x 14 patch holds its
+// middle rows / columns 1 .. 14 and the rest (about a third of the samples) takes the far path - still 2 - 3 x faster than the gather kernel.
+__device__ __forceinline__ int pp_origin(int stride) { return stride == 1 ? 3 : -1; }
+
+__device__ __forceinline__ uint4 pp_make_entry(bool pixel_in_image, int yy, int xx, int kh, int kw, float2 ov, int ty, int tx, int H, int W,
+                                               int stride) {
+    const int org = pp_origin(stride);
+    const float t_fy = (float)(stride * yy + kh - 1 + org), t_fx = (float)(stride * xx + kw - 1 + org);   // undeformed sample, patch coordinates
+    const float py0 = (float)(ty * 8 * stride - org), px0 = (float)(tx * 8 * stride - org);
     const float fH = (float)H, fW = (float)W;
     unsigned s0 = pp_slot(pp::NPIX, 0), s1 = s0, s2 = s0, s3 = s0;        // the zero pixel: contributes nothing
     float lh = 0.f, lw = 0.f;
@@ -111,7 +119,7 @@ __device__ __forceinline__ uint4 pp_make_entry(bool pixel_in_image, float t_fy, 
                 const int u = hl * pp::PS + wl;
                 s0 = pp_slot(u, 0); s1 = pp_slot(u + 1, 0); s2 = pp_slot(u + pp::PS, 0); s3 = pp_slot(u + pp::PS + 1, 0);
             } else {
-                const int ih = hl + ty * 8 - 3, iw = wl + tx * 8 - 3;     // |.| < 2^15: feature maps are a few thousand pixels at most
+                const int ih = hl + ty * 8 * stride - org, iw = wl + tx * 8 * stride - org;     // |.| < 2^15: feature maps are a few thousand pixels at most
                 e.x = (unsigned)(ih + 32768) | ((unsigned)(iw + 32768) << 16);
                 e.y = pp::FAR_Y;
                 e.z = __float_as_uint(lh); e.w = __float_as_uint(lw);
@@ -161,13 +169,14 @@ __global__ __launch_bounds__(256) void deform_offsets_table_kernel(const float* 
             ov = make_float2(a0, a1);
             *reinterpret_cast<float2*>(offsets + (((size_t)tn * H + oy) * W + ox) * 18 + 2 * k) = ov;
         }
-        table[i] = pp_make_entry(in, (float)(yy + kh + 2), (float)(xx + kw + 2), ov, ty, tx, H, W);
+        table[i] = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, H, W, 1);
     }
 }
 
 // The same table from an offsets tensor (N, H, W, 18) that already exists (callers without the fused pre-pass).
-__global__ __launch_bounds__(256) void deform_table_kernel(const float* __restrict__ offsets, int batch, int H, int W,
-                                                          uint4* __restrict__ table) {
+// H, W: the OUTPUT grid (tiles, offsets); Hin, Win: the sampled image (== H, W at stride 1).
+__global__ __launch_bounds__(256) void deform_table_kernel(const float* __restrict__ offsets, int batch, int Hin, int Win, int H, int W,
+                                                          int stride, uint4* __restrict__ table) {
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const long total = (long)batch * tiles_y * tiles_x * pp::NE;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void deform_table_kernel(const float* __restri
         const bool in = oy < H && ox < W;
         float2 ov = make_float2(0.f, 0.f);
         if (in) ov = *reinterpret_cast<const float2*>(offsets + (((size_t)tn * H + oy) * W + ox) * 18 + 2 * k);
-        table[i] = pp_make_entry(in, (float)(yy + kh + 2), (float)(xx + kw + 2), ov, ty, tx, H, W);
+        table[i] = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, Hin, Win, stride);
     }
 }
 
@@ -192,7 +201,9 @@ __global__ __launch_bounds__(256) void deform_table_kernel(const float* __restri
 template <int CG, bool BF3 = false>
 __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     const float* __restrict__ x, const float* __restrict__ wfrag, const float* __restrict__ scale, const float* __restrict__ bias,
-    int relu, int batch, int H, int W, int C, int Cout, int nsplit, float* __restrict__ y, const uint4* __restrict__ table) {
+    int relu, int batch, int H, int W, int Ho, int Wo, int stride, int C, int Cout, int nsplit, float* __restrict__ y,
+    const uint4* __restrict__ table) {
+    // H, W: the sampled image; Ho, Wo: the output grid (== H, W at stride 1); stride 1 or 2 (pp_origin)
     static_assert(CG == 32 || CG == 16, "32 channels per group, or two groups of 16 per item");
     static_assert(!BF3 || CG == 32, "the bf16x3 experiment exists for 32 channels per group only");
     constexpr int NQ = CG == 32 ? 4 : 2;                     // float4 weight fragments per lane and tap
@@ -205,8 +216,9 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: scalar branches on team / slot
     const int team = wave >> 2, m = wave & 3;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
     const int ntiles = batch * tiles_y * tiles_x;
+    const int org = pp_origin(stride), tstep = 8 * stride;                                 // patch origin = tile * tstep - org
     const int g = blockIdx.x / nsplit, sidx = blockIdx.x - g * nsplit;                     // g = item (32 channels)
     // contiguous tile range of this workgroup
     const int tq = ntiles / nsplit, trm = ntiles - tq * nsplit;
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     const unsigned patch_b0 = PATCH0 + (unsigned)team * 2u * pp::PATCH_B;                  // this team's patch buffer 0
     const unsigned tab_b0 = TAB0 + (unsigned)team * 2u * pp::TAB_B;                        // ... table buffer 0
     const int c0 = g * pp::CH;
-    const long HW = (long)H * W;
+    const long HW = (long)H * W, HWo = (long)Ho * Wo;
     const char* xb = reinterpret_cast<const char*>(x);
 
     // ---- per-thread constants of the patch fill (no division inside the loop) ------------------------------------
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
     };
     auto issue_patch = [&](const TileXY& T, unsigned base) {
-        const int py0 = T.ty * 8 - 3, px0 = T.tx * 8 - 3;
+        const int py0 = T.ty * tstep - org, px0 = T.tx * tstep - org;
         const char* pbase = xb + (((long)T.tn * HW + (long)py0 * W + px0) * C + c0) * 4;
         const bool inner = py0 >= 0 && px0 >= 0 && py0 + pp::PS <= H && px0 + pp::PS <= W;
         if (inner) {
@@ -373,8 +385,8 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     auto epilogue = [&]() {
         if (!prev_valid) return;
         const int ho = prev.ty * 8 + my_y, wo = prev.tx * 8 + my_x;
-        if (ho < H && wo < W) {
-            float* dst = y + ((long)prev.tn * HW + (long)ho * W + wo) * Cout + c0 + 4 * kq;
+        if (ho < Ho && wo < Wo) {
+            float* dst = y + ((long)prev.tn * HWo + (long)ho * Wo + wo) * Cout + c0 + 4 * kq;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const float4 sc = aff_sc[nt], bi = aff_bi[nt];
@@ -607,9 +619,10 @@ static int scratch_table(size_t bytes, hipStream_t stream, void** out) {
     return WT_OK;
 }
 
-// launcher used by wd_deform_conv3x3_f32 (det_deform.hip); cg = channels per group (32 or 16)
+// launcher used by wd_deform_conv3x3_f32 (det_deform.hip); cg = channels per group (32 or 16), stride 1 or 2 (pad 1); `table` (stride 1
+// only: built by wd_deform_offsets_table_f32 on the same h x w) or NULL = built here from `offset` into the scratch buffer
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
-                        const float* bias, int relu, int batch, int h, int w, int c, int cg, hipStream_t stream, float* y,
+                        const float* bias, int relu, int batch, int h, int w, int c, int cg, int stride, hipStream_t stream, float* y,
                         const void* table) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -619,16 +632,17 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<16>()));
         attr_set = true;
     }
+    const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
     const int items = c / pp::CH;
-    const int ntiles = batch * ((h + 7) / 8) * ((w + 7) / 8);
-    if (!table) {
+    const int ntiles = batch * ((ho + 7) / 8) * ((wo + 7) / 8);
+    if (!table || stride != 1) {
         void* scratch = nullptr;
-        const size_t bytes = (size_t)ntiles * pp::TAB_B;
-        WT_TRY(scratch_table(bytes, stream, &scratch));
+        WT_TRY(scratch_table(wd_deform_table_bytes(batch, ho, wo), stream, &scratch));
         const long total = (long)ntiles * pp::NE;
         long blocks = (total + 255) / 256;
         if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(deform_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, offset, batch, h, w, (uint4*)scratch);
+        hipLaunchKernelGGL(deform_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, offset, batch, h, w, ho, wo, stride,
+                           (uint4*)scratch);
         WT_HIP(hipGetLastError());
         table = scratch;
     }
@@ -646,6 +660,7 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
     if (nsplit < 1) nsplit = 1;
     const float* wfrag = packed_weight + (size_t)c * cg * 9;       // lane-major fragment copy (pack_weight_kernel)
     static const bool bf3 = getenv("WD_DEFORM_BF16X3") && getenv("WD_DEFORM_BF16X3")[0] == '1';     // EXPERIMENT: not fp32 (see the kernel's header)
+    const dim3 grid((unsigned)(items * nsplit));
     if (cg == 32 && bf3) {
         static bool attr3 = false;
         if (!attr3) {
@@ -653,14 +668,14 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<32>()));
             attr3 = true;
         }
-        hipLaunchKernelGGL((deform_conv3x3_pp_kernel<32, true>), dim3((unsigned)(items * nsplit)), dim3(512), pp::smem_bytes<32>(), stream, x,
-                           wfrag, scale, bias, relu, batch, h, w, c, c, nsplit, y, (const uint4*)table);
+        hipLaunchKernelGGL((deform_conv3x3_pp_kernel<32, true>), grid, dim3(512), pp::smem_bytes<32>(), stream, x, wfrag, scale, bias, relu,
+                           batch, h, w, ho, wo, stride, c, c, nsplit, y, (const uint4*)table);
     } else if (cg == 32)
-        hipLaunchKernelGGL(deform_conv3x3_pp_kernel<32>, dim3((unsigned)(items * nsplit)), dim3(512), pp::smem_bytes<32>(), stream, x,
-                           wfrag, scale, bias, relu, batch, h, w, c, c, nsplit, y, (const uint4*)table);
+        hipLaunchKernelGGL(deform_conv3x3_pp_kernel<32>, grid, dim3(512), pp::smem_bytes<32>(), stream, x, wfrag, scale, bias, relu, batch,
+                           h, w, ho, wo, stride, c, c, nsplit, y, (const uint4*)table);
     else
-        hipLaunchKernelGGL(deform_conv3x3_pp_kernel<16>, dim3((unsigned)(items * nsplit)), dim3(512), pp::smem_bytes<16>(), stream, x,
-                           wfrag, scale, bias, relu, batch, h, w, c, c, nsplit, y, (const uint4*)table);
+        hipLaunchKernelGGL(deform_conv3x3_pp_kernel<16>, grid, dim3(512), pp::smem_bytes<16>(), stream, x, wfrag, scale, bias, relu, batch,
+                           h, w, ho, wo, stride, c, c, nsplit, y, (const uint4*)table);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
