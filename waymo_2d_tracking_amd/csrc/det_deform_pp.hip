@@ -28,6 +28,7 @@
 //     channels of its pixel -> the epilogue (FrozenBN affine + ReLU) writes 16 bytes per lane and 16-channel tile.
 // LDS (32 channels per group): 24 576 (weights of 6 taps) + 4 x 25 216 (patches) + 4 x 9 216 (tables) = 162 304 bytes.
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "common.h"
 #include "../../include/waymodet.h"
@@ -597,10 +598,14 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
 
 }  // namespace
 
-// scratch table for callers that pass offsets without a pre-built table (tests, tools, training-free paths): grown on demand
+// scratch table for callers that pass offsets without a pre-built table (stride-2 layers, tests, tools, the training forward): grown on
+// demand, one process = one GPU.  A buffer that has been handed out may be baked into a captured hipGraph, so it is never freed or moved:
+// growing allocates a NEW buffer and keeps the old one alive (a few MB per distinct size class, once).
 static int scratch_table(size_t bytes, hipStream_t stream, void** out) {
+    static std::mutex mu;
     static void* buf = nullptr;
     static size_t cap = 0;
+    std::lock_guard<std::mutex> lock(mu);
     if (bytes > cap) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &st);
@@ -609,11 +614,11 @@ static int scratch_table(size_t bytes, hipStream_t stream, void** out) {
                           "or pass a table (wd_deform_offsets_table_f32)");
             return WT_ERR_INVALID;
         }
-        WT_HIP(hipDeviceSynchronize());
-        if (buf) (void)hipFree(buf);
-        buf = nullptr; cap = 0;
-        WT_HIP(hipMalloc(&buf, bytes));
-        cap = bytes;
+        void* fresh = nullptr;
+        const size_t want = bytes + bytes / 4;                   // head room: fewer size classes
+        WT_HIP(hipMalloc(&fresh, want));
+        buf = fresh;                                             // the previous buffer stays allocated (see above)
+        cap = want;
     }
     *out = buf;
     return WT_OK;
