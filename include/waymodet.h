@@ -197,6 +197,23 @@ int wd_tap_shift_add_f32(const float* partial, int ld, int n_out, const float* b
 /* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
 int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
 
+/* GPU JPEG decode: replaces `PIL.Image.open(path).convert('RGB')` of the reference's loader
+ * (detnet/data/coco.py image read + detnet/inference.py:170 ToRGB), i.e. libjpeg-turbo at its defaults (baseline Huffman,
+ * JDCT_ISLOW, fancy upsampling, jdcolor YCbCr -> RGB); bit-exact with it.  Entropy decoding runs on the GPU by
+ * self-synchronising 1024-bit subsequences (csrc/jpeg_core.h); only marker parsing and byte unstuffing stay on the host.
+ *   data / n   : HOST pointer to the file bytes
+ *   rgb        : DEVICE buffer of `capacity` bytes, receives (height, width, 3) uint8 RGB (grayscale files replicated,
+ *                as convert('RGB') does) - the layout wd_preprocess_f32 takes as WD_LAYOUT_NHWC_U8
+ *   sync_rounds: optional, number of synchronisation launches it took (3 unless the stream is adversarial)
+ * The call returns when the image is complete (it synchronises `stream`).  Supported: 8-bit baseline / extended
+ * sequential Huffman, one interleaved scan, grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals.  Anything else
+ * (progressive, arithmetic, CMYK, multi-scan, truncated data) is WT_ERR_INVALID with the reason in wt_last_error().
+ * wd_jpeg_info parses the headers only (host-only, no GPU needed); restart_interval = 0 when the file has no DRI. */
+int wd_jpeg_info(const uint8_t* data, int64_t n, int32_t* width, int32_t* height, int32_t* components, int32_t* h_samp,
+                 int32_t* v_samp, int32_t* restart_interval);
+int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rgb, int64_t capacity, int32_t* width, int32_t* height,
+                          int32_t* sync_rounds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

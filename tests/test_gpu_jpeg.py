@@ -1,0 +1,72 @@
+"""GPU JPEG decoder (csrc/jpeg_decode.hip) against PIL - the decoder the reference uses
+(detnet/inference.py:170 ToRGB on `Image.open`): bit-exact RGB on every case."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+import jpeg_cases as JC                                                                      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_decode_is_bit_exact_with_pil_small_and_medium():
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    bad = []
+    for name, data in JC.small_cases() + JC.medium_cases():
+        got, rounds = ops.jpeg_decode(data, return_rounds=True)
+        exp = JC.pil_rgb(data)
+        if got.shape != exp.shape or not np.array_equal(got.cpu().numpy(), exp) or rounds != 3:
+            bad.append((name, rounds))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('h,w,sub,q', [(1280, 1920, 2, 90), (886, 1920, 2, 95), (1280, 1920, 0, 100)])
+def test_decode_full_size_frames(h, w, sub, q):
+    """BASELINE config sizes (front 1920x1280 and side 1920x886 cameras); quality 100 / 4:4:4 noise = 10 MB of scan data,
+    the largest stream the path sees"""
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    data = JC.encode(JC.synth(h, w, 1 if q == 100 else 2, seed=7), quality=q, subsampling=sub)
+    got, rounds = ops.jpeg_decode(data, return_rounds=True)
+    assert rounds == 3
+    assert torch.equal(got.cpu(), torch.from_numpy(JC.pil_rgb(data).copy()))
+    assert ops.jpeg_info(data)[:3] == (w, h, 3)
+
+
+def test_decode_rejects_unsupported_flavours_loudly():
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    from waymo_2d_tracking_amd._lib import WaymoTrackError
+    with pytest.raises(WaymoTrackError, match='progressive'):
+        ops.jpeg_decode(JC.encode(JC.synth(32, 32, 2), quality=80, progressive=True))
+    data = JC.medium_cases()[0][1]
+    with pytest.raises(WaymoTrackError, match='truncated|ends before'):
+        ops.jpeg_decode(data[:len(data) // 2])
+    with pytest.raises(WaymoTrackError):
+        ops.jpeg_decode(b'not a jpeg at all')
+    # and the decoder still works afterwards (contexts are released on the error paths)
+    assert np.array_equal(ops.jpeg_decode(data).cpu().numpy(), JC.pil_rgb(data))
+
+
+def test_image_loader_decodes_jpeg_on_the_gpu(tmp_path):
+    """the loader's thread pool: 4 threads, own streams, 12 files of different sizes - every frame equals PIL's decode, and
+    the 'pil' decoder gives the same tensors"""
+    from waymo_2d_tracking_amd.detnet.inference import ImageLoader
+    items = []
+    for i in range(12):
+        h, w = 120 + 16 * i, 200 + 24 * (i % 5)
+        path = str(tmp_path / ('%02d.jpg' % i))
+        with open(path, 'wb') as f:
+            f.write(JC.encode(JC.synth(h, w, 2, seed=i), quality=70 + 2 * i, subsampling=(2, 1, 0)[i % 3]))
+        items.append((i, path))
+    png = str(tmp_path / 'x.png')
+    from PIL import Image
+    Image.fromarray(JC.synth(40, 50, 0)).save(png)
+    items.append((99, png))
+    gpu = list(ImageLoader(items, workers=4, depth=6, decoder='gpu'))
+    host = list(ImageLoader(items, workers=4, depth=6, decoder='pil'))
+    assert [g[0] for g in gpu] == [i for i, _ in items]
+    for (ia, ta, sa), (ib, tb, sb) in zip(gpu, host):
+        assert ia == ib and sa == sb and ta.dtype == torch.uint8 and torch.equal(ta.cpu(), tb.cpu())

@@ -1,0 +1,99 @@
+"""CPU side of the JPEG decoder row: the sequential restatement (oracle/jpeg_ref.py) is pinned bit for bit
+against PIL - the reference's own decoder (detnet/inference.py:170 ToRGB on PIL images) - and the parallel
+synchronisation scheme of csrc/jpeg_decode.hip, emulated thread by thread on the CPU from the same header
+(tests/native/jpeg_sync_emul.cpp + csrc/jpeg_core.h / jpeg_host.h), reproduces the sequential coefficients."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import jpeg_cases as JC                                                                      # noqa: E402
+from oracle import jpeg_ref as J                                                             # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_restatement_is_bit_exact_with_pil():
+    bad = []
+    for name, data in JC.small_cases():
+        if not np.array_equal(J.decode_rgb(data), JC.pil_rgb(data)):
+            bad.append(name)
+    assert not bad, bad
+
+
+def test_restatement_rejects_what_the_gpu_decoder_rejects():
+    prog = JC.encode(JC.synth(32, 32, 2), quality=80, progressive=True)
+    with pytest.raises(J.Unsupported):
+        J.decode_rgb(prog)
+    with pytest.raises(ValueError):
+        J.decode_rgb(b'\x89PNG\r\n\x1a\n' + bytes(32))
+
+
+@pytest.fixture(scope='module')
+def emul(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp('jpeg') / 'libjpeg_emul.so')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-o', so, os.path.join(ROOT, 'tests', 'native', 'jpeg_sync_emul.cpp')],
+                   check=True)
+    lib = ctypes.CDLL(so)
+
+    def run(data, group=256):
+        cap = 1 << 17
+        coef = np.zeros((cap, 64), np.int16)
+        rounds, total = ctypes.c_int(0), ctypes.c_int(0)
+        geo = (ctypes.c_int * 8)()
+        err = ctypes.create_string_buffer(256)
+        rc = lib.jpeg_emul_coefficients(data, ctypes.c_long(len(data)), group, coef.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(cap),
+                                        ctypes.byref(rounds), ctypes.byref(total), geo, err, 256)
+        if rc:
+            raise RuntimeError(err.value.decode())
+        return coef[:total.value], rounds.value, list(geo)
+    return run
+
+
+def scan_order(info, planes):
+    hmax, vmax, shape, mx, my = J.geometry(info)
+    out = []
+    for m in range(mx * my):
+        my_i, mx_i = divmod(m, mx)
+        for ci, (h, v) in enumerate(shape):
+            for by in range(v):
+                for bx in range(h):
+                    out.append(planes[ci][my_i * v + by, mx_i * h + bx])
+    return np.stack(out)
+
+
+def test_parallel_entropy_decode_equals_sequential(emul):
+    """every subsequence settles on the sequential decoder's state: coefficients identical, for workgroups of 256 threads
+    (the GPU's) and of 4 (many more cross-workgroup hand-overs)"""
+    cases = JC.small_cases() + JC.medium_cases()[:5]
+    for name, data in cases:
+        info = J.parse(data)
+        exp = scan_order(info, J.decode_coefficients(info))
+        for group in (256, 4):
+            got, rounds, geo = emul(data, group)
+            assert got.shape == exp.shape and np.array_equal(got, exp), (name, group)
+            if group == 256:
+                assert rounds == 3, (name, rounds)                     # the fixed three launches suffice
+
+
+def test_emulation_reports_truncated_streams(emul):
+    name, data = JC.medium_cases()[0]
+    with pytest.raises(RuntimeError):
+        emul(data[:len(data) // 2])
+
+
+def test_header_parse_needs_no_gpu():
+    """wd_jpeg_info is host-only (the C-ABI library loads and answers without a device)"""
+    from waymo_2d_tracking_amd import _lib
+    lib = _lib.lib()
+    data = JC.encode(JC.synth(50, 70, 2), quality=90, subsampling=2, restart_marker_blocks=3)
+    o = [ctypes.c_int32(0) for _ in range(6)]
+    assert lib.wd_jpeg_info(data, ctypes.c_int64(len(data)), *[ctypes.byref(v) for v in o]) == 0
+    assert [v.value for v in o][:5] == [70, 50, 3, 2, 2] and o[5].value > 0
+    prog = JC.encode(JC.synth(32, 32, 2), quality=80, progressive=True)
+    assert lib.wd_jpeg_info(prog, ctypes.c_int64(len(prog)), *[ctypes.byref(v) for v in o]) != 0
+    assert b'progressive' in lib.wt_last_error()

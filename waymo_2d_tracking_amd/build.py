@@ -37,6 +37,7 @@ UNITS = {
     'det_gemm_lt.hip': [],
     'det_misc.hip': [],
     'det_preprocess.hip': ['-ffp-contract=off'],
+    'jpeg_decode.hip': [],
     'det_tail.hip': ['-ffp-contract=off'],
     'det_backward.hip': ['-munsafe-fp-atomics'],
 }

@@ -1,0 +1,558 @@
+// GPU JPEG decode - see jpeg_core.h for the scheme.  One call = one image:
+//   host   : marker parse, Huffman / quantisation tables, byte unstuffing into restart segments (a memchr pass), one
+//            pinned staging blob -> ONE hipMemcpyAsync
+//   device : jpeg_sync_kernel (x3)  - subsequence synchronisation, bitstream + tables in LDS
+//            jpeg_scan_kernel       - chain check + first block index of every subsequence (segmented scan)
+//            jpeg_write_kernel      - final decode pass, coefficients (int16, natural order) to HBM
+//            jpeg_dc_kernel         - DC prediction = segmented prefix sum per component
+//            jpeg_idct_kernel       - dequantise + jidctint.c islow, 8 threads per block, planes in u8
+//            jpeg_color_kernel      - fancy h2v1 / h2v2 upsampling + YCbCr -> RGB, (H, W, 3) u8 out
+// The call returns after its stream has drained (it has to read the "chain settled" flag); when the flag is not set
+// after three rounds (adversarial streams) it keeps launching sync rounds until it is and repeats the tail.
+#include <mutex>
+#include <vector>
+#include "common.h"
+#include "jpeg_core.h"
+#include "jpeg_host.h"
+#include "../../include/waymodet.h"
+
+namespace {
+
+using jd::Header;
+using jd::HuffLut;
+using jd::State;
+using jdh::Layout;
+using jdh::Parsed;
+
+constexpr int kSyncThreads = 256;
+constexpr int kLdsWords = kSyncThreads * jd::SUB_WORDS + 2;
+
+// ---------------------------------------------------------------------------------------------------------------- host
+int fail(const char* msg) {
+    wt::set_error("wd_jpeg: %s", msg);
+    return WT_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------------------- kernels
+struct Dev {                         // device pointers into the blob + work buffers
+    const Header* hd;
+    const HuffLut* luts;
+    const uint32_t* seg_first_sub;
+    const uint32_t* seg_end_bit;
+    const int32_t* sub_seg;
+    State* start;
+    State* exit;
+    const uint32_t* stream;          // bytes as stored (big-endian bit order): words are byte-swapped on load
+    int32_t* nblk;                   // blocks completed per subsequence
+    int32_t* base;                   // first block index per subsequence
+    int16_t* coef;
+    uint8_t* planes;
+    int32_t* flags;                  // [0] chain not settled, [1] a segment came up short
+    int nsub, stream_words;
+};
+
+__device__ __forceinline__ void stage(const Dev& d, uint32_t* words, HuffLut* luts) {
+    const uint32_t w0 = blockIdx.x * (uint32_t)(kSyncThreads * jd::SUB_WORDS);
+    for (int j = threadIdx.x; j < kLdsWords; j += kSyncThreads) {
+        const uint32_t g = w0 + (uint32_t)j;
+        words[j] = g < (uint32_t)d.stream_words ? __builtin_bswap32(d.stream[g]) : 0xFFFFFFFFu;
+    }
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(d.luts);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(luts);
+    for (int j = threadIdx.x; j < (int)(4 * sizeof(HuffLut) / 4); j += kSyncThreads) dst[j] = src[j];
+}
+
+__global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
+    __shared__ uint32_t words[kLdsWords];
+    __shared__ HuffLut luts[4];
+    __shared__ State exits[kSyncThreads];
+    __shared__ Header hd;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kSyncThreads + tid;
+    const bool valid = i < d.nsub;
+    stage(d, words, luts);
+    for (int j = tid; j < (int)(sizeof(Header) / 4); j += kSyncThreads) reinterpret_cast<uint32_t*>(&hd)[j] = reinterpret_cast<const uint32_t*>(d.hd)[j];
+    const uint32_t w0 = blockIdx.x * (uint32_t)(kSyncThreads * jd::SUB_WORDS);
+    int seg = 0;
+    bool first = false;
+    uint32_t seg_end = 0, bound = 0;
+    State s_cur{jd::NO_STATE, jd::NO_STATE}, e_cur{0, 0}, from_prev{0, 0};
+    int n_cur = 0;
+    if (valid) {
+        seg = d.sub_seg[i];
+        first = d.seg_first_sub[seg] == (uint32_t)i;
+        seg_end = d.seg_end_bit[seg];
+        bound = (uint32_t)(i + 1) * jd::SUB_BITS;
+        bound = bound < seg_end ? bound : seg_end;
+        s_cur = d.start[i];
+        e_cur = d.exit[i];
+        n_cur = d.nblk[i];
+        if (tid == 0 && !first) from_prev = d.exit[i - 1];
+    }
+    exits[tid] = e_cur;
+    __syncthreads();
+    for (;;) {
+        State want;
+        if (first) { want.p = (uint32_t)i * jd::SUB_BITS; want.bk = 0; }
+        else want = tid == 0 ? from_prev : exits[tid - 1];
+        __syncthreads();
+        int changed = 0;
+        if (valid && !jd::same(want, s_cur)) {
+            s_cur = want;
+            int n = 0;
+            const State e = jd::run<false>(s_cur, bound, seg_end, words, w0, luts, &hd, n, nullptr, 0, 0);
+            n_cur = n;
+            if (!jd::same(e, e_cur)) { e_cur = e; exits[tid] = e; changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    if (valid) { d.start[i] = s_cur; d.exit[i] = e_cur; d.nblk[i] = n_cur; }
+}
+
+// one workgroup: is every start state the exit state of its predecessor (or the known segment start)?  first block index
+// of every subsequence = blocks of its segment before it (segmented exclusive scan over nblk)
+__global__ __launch_bounds__(1024) void jpeg_scan_kernel(Dev d) {
+    __shared__ int vals[1024];
+    __shared__ int flgs[1024];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x;
+    const Header* hd = d.hd;
+    const int bpm = hd->bpm, ri = hd->ri, total = hd->total_blocks;
+    if (tid == 0) carry_s = 0;
+    int bad = 0, shortfall = 0;
+    for (int c0 = 0; c0 < d.nsub; c0 += 1024) {
+        const int i = c0 + tid;
+        int n = 0, f = 0, seg = 0;
+        if (i < d.nsub) {
+            seg = d.sub_seg[i];
+            f = d.seg_first_sub[seg] == (uint32_t)i;
+            n = d.nblk[i];
+            const State s = d.start[i];
+            State want;
+            if (f) { want.p = (uint32_t)i * jd::SUB_BITS; want.bk = 0; } else want = d.exit[i - 1];
+            bad |= !jd::same(s, want);
+        }
+        __syncthreads();
+        vals[tid] = n;
+        flgs[tid] = f;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {                         // inclusive segmented scan
+            int v = vals[tid], g = flgs[tid];
+            if (tid >= off && !g) { v += vals[tid - off]; g = flgs[tid - off]; }
+            __syncthreads();
+            vals[tid] = v;
+            flgs[tid] = g;
+            __syncthreads();
+        }
+        const int incl = vals[tid] + (flgs[tid] ? 0 : carry_s);            // blocks of the segment up to and including i
+        if (i < d.nsub) {
+            const int seg_block0 = seg * ri * bpm;
+            d.base[i] = seg_block0 + incl - n;
+            if (d.seg_first_sub[seg + 1] == (uint32_t)(i + 1)) {             // last subsequence of its segment
+                int expect = total - seg_block0;
+                expect = expect < ri * bpm ? expect : ri * bpm;
+                shortfall |= incl < expect;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = incl;
+        __syncthreads();
+    }
+    if (bad) atomicOr(&d.flags[0], 1);
+    if (shortfall) atomicOr(&d.flags[1], 1);
+}
+
+__global__ __launch_bounds__(kSyncThreads) void jpeg_write_kernel(Dev d) {
+    __shared__ uint32_t words[kLdsWords];
+    __shared__ HuffLut luts[4];
+    __shared__ Header hd;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kSyncThreads + tid;
+    stage(d, words, luts);
+    for (int j = tid; j < (int)(sizeof(Header) / 4); j += kSyncThreads) reinterpret_cast<uint32_t*>(&hd)[j] = reinterpret_cast<const uint32_t*>(d.hd)[j];
+    __syncthreads();
+    if (i >= d.nsub) return;
+    const uint32_t w0 = blockIdx.x * (uint32_t)(kSyncThreads * jd::SUB_WORDS);
+    const int seg = d.sub_seg[i];
+    const uint32_t seg_end = d.seg_end_bit[seg];
+    uint32_t bound = (uint32_t)(i + 1) * jd::SUB_BITS;
+    bound = bound < seg_end ? bound : seg_end;
+    const int seg_block0 = seg * hd.ri * hd.bpm;
+    int block_end = seg_block0 + hd.ri * hd.bpm;
+    block_end = block_end < hd.total_blocks ? block_end : hd.total_blocks;
+    int n = 0;
+    const State s = d.start[i];
+    if (s.p == jd::NO_STATE || s.p < w0 * 32u) return;                    // never for a settled chain
+    (void)jd::run<true>(s, bound, seg_end, words, w0, luts, &hd, n, d.coef, d.base[i], block_end);
+}
+
+// DC prediction: coefficient 0 of the t-th block of component c (scan order) = sum of the differences since the start of
+// its restart segment.  One workgroup per component, 8 blocks per thread and round, segmented scan across the threads.
+__global__ __launch_bounds__(1024) void jpeg_dc_kernel(Dev d) {
+    constexpr int ITEMS = 8;
+    __shared__ int vals[1024];
+    __shared__ int flgs[1024];
+    __shared__ int carry_s;
+    const Header* hd = d.hd;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int nb = hd->comp_nblk[c], off = hd->comp_off[c], bpm = hd->bpm, ri = hd->ri;
+    const int len = hd->mx * hd->my * nb;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < len; c0 += 1024 * ITEMS) {
+        const int t0 = c0 + tid * ITEMS;
+        int v[ITEMS];
+        int run = 0, any_reset = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int t = t0 + j;
+            int diff = 0, reset = 0;
+            if (t < len) {
+                const int mcu = t / nb, jj = t - mcu * nb;
+                reset = jj == 0 && mcu % ri == 0;
+                diff = d.coef[(size_t)(mcu * bpm + off + jj) * 64];
+            }
+            run = reset ? diff : run + diff;
+            any_reset |= reset;
+            v[j] = run;
+        }
+        vals[tid] = run;
+        flgs[tid] = any_reset;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int a = vals[tid], g = flgs[tid];
+            if (tid >= o && !g) { a += vals[tid - o]; g = flgs[tid - o]; }
+            __syncthreads();
+            vals[tid] = a;
+            flgs[tid] = g;
+            __syncthreads();
+        }
+        // carry into this thread = inclusive value of the previous thread (+ the chunk carry if no reset before it)
+        int carry = 0;
+        if (tid > 0) carry = vals[tid - 1] + (flgs[tid - 1] ? 0 : carry_s); else carry = carry_s;
+        const int last_incl = vals[1023] + (flgs[1023] ? 0 : carry_s);
+        bool seen = false;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int t = t0 + j;
+            if (t < len) {
+                const int mcu = t / nb, jj = t - mcu * nb;
+                seen |= jj == 0 && mcu % ri == 0;
+                d.coef[(size_t)(mcu * bpm + off + jj) * 64] = (int16_t)(v[j] + (seen ? 0 : carry));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = last_incl;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// jidctint.c: one 1-D pass of the "islow" inverse DCT on 8 values
+__device__ __forceinline__ void islow_pass(const int* in, int* out, int out_shift) {
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * 4433;
+    int tmp2 = z1 + z3 * -15137;
+    int tmp3 = z1 + z2 * 6270;
+    int tmp0 = (in[0] + in[4]) << 13;
+    int tmp1 = (in[0] - in[4]) << 13;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * 9633;
+    tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
+    z1 *= -7373; z2 *= -20995; z3 = z3 * -16069 + z5; z4 = z4 * -3196 + z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = descale(tmp10 + tmp3, out_shift); out[7] = descale(tmp10 - tmp3, out_shift);
+    out[1] = descale(tmp11 + tmp2, out_shift); out[6] = descale(tmp11 - tmp2, out_shift);
+    out[2] = descale(tmp12 + tmp1, out_shift); out[5] = descale(tmp12 - tmp1, out_shift);
+    out[3] = descale(tmp13 + tmp0, out_shift); out[4] = descale(tmp13 - tmp0, out_shift);
+}
+
+// 32 blocks per workgroup, 8 threads per block: dequantise -> column pass -> row pass -> range limit -> u8 plane
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(Dev d) {
+    constexpr int BS = 72, RS = 9;                   // LDS strides (ints): block, row - conflict-free in both passes
+    __shared__ int ws[32 * BS];
+    const Header* hd = d.hd;
+    const int tid = threadIdx.x, lb = tid >> 3, l = tid & 7;
+    const int b = blockIdx.x * 32 + lb;
+    const bool valid = b < hd->total_blocks;
+    int comp = 0, px = 0, py = 0;
+    if (valid) {
+        const int mcu = b / hd->bpm, j = b - mcu * hd->bpm;
+        comp = hd->blk_comp[j];
+        const int jj = j - hd->comp_off[comp];
+        const int h = hd->comp_h[comp], v = hd->comp_v[comp];
+        const int my = mcu / hd->mx, mxi = mcu - my * hd->mx;
+        px = (mxi * h + jj % h) * 8;
+        py = (my * v + jj / h) * 8;
+        const uint4 raw = *reinterpret_cast<const uint4*>(d.coef + (size_t)b * 64 + l * 8);
+        const uint16_t* q = hd->quant[hd->comp_tq[comp]] + l * 8;
+        const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ws[lb * BS + l * RS + 2 * k] = (int)(int16_t)(r[k] & 0xffff) * (int)q[2 * k];
+            ws[lb * BS + l * RS + 2 * k + 1] = (int)(int16_t)(r[k] >> 16) * (int)q[2 * k + 1];
+        }
+    }
+    __syncthreads();
+    if (valid) {                                      // pass 1: column l
+        int in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = ws[lb * BS + r * RS + l];
+        islow_pass(in, out, 13 - 2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[lb * BS + r * RS + l] = out[r];
+    }
+    __syncthreads();
+    if (valid) {                                      // pass 2: row l
+        int in[8], out[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in[k] = ws[lb * BS + l * RS + k];
+        islow_pass(in, out, 13 + 2 + 3);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = out[k] & 1023;              // RANGE_MASK on the table centred at 128
+            const uint32_t u = (uint32_t)(v < 128 ? v + 128 : v < 512 ? 255 : v < 896 ? 0 : v - 896);
+            if (k < 4) lo |= u << (8 * k); else hi |= u << (8 * (k - 4));
+        }
+        uint8_t* row = d.planes + hd->plane_off[comp] + (size_t)(py + l) * hd->plane_pitch[comp] + px;
+        *reinterpret_cast<uint2*>(row) = make_uint2(lo, hi);
+    }
+}
+
+__device__ __forceinline__ void ycc_to_rgb(int y, int cb, int cr, uint8_t* out) {
+    cb -= 128; cr -= 128;
+    int r = y + ((91881 * cr + 32768) >> 16);
+    int g = y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    int b = y + ((116130 * cb + 32768) >> 16);
+    out[0] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+    out[1] = (uint8_t)(g < 0 ? 0 : g > 255 ? 255 : g);
+    out[2] = (uint8_t)(b < 0 ? 0 : b > 255 ? 255 : b);
+}
+
+// MODE 0: 4:4:4, 1: h2v1, 2: h2v2, 3: grayscale.  One thread = one chroma site = FH x FV output pixels.
+template <int MODE>
+__global__ __launch_bounds__(256) void jpeg_color_kernel(Dev d, uint8_t* __restrict__ rgb) {
+    const Header* hd = d.hd;
+    const int W = hd->width, H = hd->height;
+    constexpr int FH = (MODE == 1 || MODE == 2) ? 2 : 1, FV = MODE == 2 ? 2 : 1;
+    const int cw = (W + FH - 1) / FH, ch = (H + FV - 1) / FV;
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63), cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cx >= cw || cy >= ch) return;
+    const uint8_t* yp = d.planes + hd->plane_off[0];
+    const int ypitch = hd->plane_pitch[0];
+    if constexpr (MODE == 3) {
+        const uint8_t v = yp[(size_t)cy * ypitch + cx];
+        uint8_t* o = rgb + ((size_t)cy * W + cx) * 3;
+        o[0] = v; o[1] = v; o[2] = v;
+        return;
+    } else {
+    const uint8_t* cbp = d.planes + hd->plane_off[1];
+    const uint8_t* crp = d.planes + hd->plane_off[2];
+    const int cpitch = hd->plane_pitch[1];
+    int cbv[FV][FH], crv[FV][FH];
+    if constexpr (MODE == 0) {
+        cbv[0][0] = cbp[(size_t)cy * cpitch + cx];
+        crv[0][0] = crp[(size_t)cy * cpitch + cx];
+    } else {
+        const int dw = hd->dw[1], dh = hd->dh[1];
+        const bool fancy = dw > 2;                    // jdsample.c: plain replication for very narrow components
+        const int xl = cx > 0 ? cx - 1 : 0, xr = cx < dw - 1 ? cx + 1 : dw - 1;
+        if constexpr (MODE == 1) {
+            const uint8_t* rb = cbp + (size_t)cy * cpitch;
+            const uint8_t* rr = crp + (size_t)cy * cpitch;
+            const int b0 = rb[cx], r0 = rr[cx];
+            if (!fancy) { cbv[0][0] = cbv[0][1] = b0; crv[0][0] = crv[0][1] = r0; }
+            else {
+                cbv[0][0] = cx == 0 ? b0 : (b0 * 3 + rb[xl] + 1) >> 2;
+                cbv[0][1] = cx == dw - 1 ? b0 : (b0 * 3 + rb[xr] + 2) >> 2;
+                crv[0][0] = cx == 0 ? r0 : (r0 * 3 + rr[xl] + 1) >> 2;
+                crv[0][1] = cx == dw - 1 ? r0 : (r0 * 3 + rr[xr] + 2) >> 2;
+            }
+        } else {
+            const int yu = cy > 0 ? cy - 1 : 0, yd = cy < dh - 1 ? cy + 1 : dh - 1;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const uint8_t* p = pl ? crp : cbp;
+                int (*o)[FH] = pl ? crv : cbv;
+                const uint8_t* r0 = p + (size_t)cy * cpitch;
+                if (!fancy) { const int v = r0[cx]; o[0][0] = o[0][1] = o[1][0] = o[1][1] = v; continue; }
+                const uint8_t* ru = p + (size_t)yu * cpitch;
+                const uint8_t* rd = p + (size_t)yd * cpitch;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const uint8_t* ro = v ? rd : ru;
+                    const int sl = 3 * r0[xl] + ro[xl], sc = 3 * r0[cx] + ro[cx], sr = 3 * r0[xr] + ro[xr];
+                    o[v][0] = cx == 0 ? (sc * 4 + 8) >> 4 : (sc * 3 + sl + 8) >> 4;
+                    o[v][1] = cx == dw - 1 ? (sc * 4 + 7) >> 4 : (sc * 3 + sr + 7) >> 4;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < FV; ++v) {
+        const int y = cy * FV + v;
+        if (y >= H) continue;
+#pragma unroll
+        for (int h = 0; h < FH; ++h) {
+            const int x = cx * FH + h;
+            if (x >= W) continue;
+            ycc_to_rgb(yp[(size_t)y * ypitch + x], cbv[v][h], crv[v][h], rgb + ((size_t)y * W + x) * 3);
+        }
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- scratch contexts
+struct Ctx {
+    uint8_t* host = nullptr;         // pinned staging blob
+    size_t host_bytes = 0;
+    uint8_t* dev = nullptr;          // device blob
+    size_t dev_bytes = 0;
+    uint8_t* work = nullptr;         // nblk | base | flags | coef | planes
+    size_t work_bytes = 0;
+    int32_t* host_flags = nullptr;   // pinned, 4 ints
+    bool busy = false;
+};
+
+std::mutex g_mu;
+std::vector<Ctx*> g_ctx;
+
+Ctx* acquire() {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (Ctx* c : g_ctx)
+        if (!c->busy) { c->busy = true; return c; }
+    Ctx* c = new Ctx();
+    c->busy = true;
+    g_ctx.push_back(c);
+    return c;
+}
+
+struct Release {
+    Ctx* c;
+    ~Release() { std::lock_guard<std::mutex> lock(g_mu); c->busy = false; }
+};
+
+int grow(Ctx& c, size_t blob, size_t work) {
+    if (!c.host_flags) WT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host_flags), 64, hipHostMallocDefault));
+    if (blob > c.host_bytes) {
+        if (c.host) (void)hipHostFree(c.host);
+        c.host = nullptr; c.host_bytes = 0;
+        const size_t want = wt::align_up(blob + blob / 4, 1 << 16);
+        WT_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host), want, hipHostMallocDefault));
+        c.host_bytes = want;
+    }
+    if (blob > c.dev_bytes) {
+        if (c.dev) (void)hipFree(c.dev);
+        c.dev = nullptr; c.dev_bytes = 0;
+        const size_t want = wt::align_up(blob + blob / 4, 1 << 16);
+        WT_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev), want));
+        c.dev_bytes = want;
+    }
+    if (work > c.work_bytes) {
+        if (c.work) (void)hipFree(c.work);
+        c.work = nullptr; c.work_bytes = 0;
+        const size_t want = wt::align_up(work + work / 4, 1 << 16);
+        WT_HIP(hipMalloc(reinterpret_cast<void**>(&c.work), want));
+        c.work_bytes = want;
+    }
+    return WT_OK;
+}
+
+}  // namespace
+
+extern "C" int wd_jpeg_info(const uint8_t* data, int64_t n, int32_t* width, int32_t* height, int32_t* components,
+                            int32_t* h_samp, int32_t* v_samp, int32_t* restart_interval) {
+    if (!data || n < 4) return fail("no data");
+    Parsed p;
+    if (const char* e = jdh::parse(data, (size_t)n, p)) return fail(e);
+    if (width) *width = p.hd.width;
+    if (height) *height = p.hd.height;
+    if (components) *components = p.hd.ncomp;
+    if (h_samp) *h_samp = p.hd.hmax;
+    if (v_samp) *v_samp = p.hd.vmax;
+    if (restart_interval) *restart_interval = p.expected_segments > 1 ? p.hd.ri : 0;
+    return WT_OK;
+}
+
+extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rgb, int64_t capacity, int32_t* width,
+                                     int32_t* height, int32_t* sync_rounds, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (!data || n < 4 || !rgb) return fail("no data / no output buffer");
+    Parsed p;
+    if (const char* e = jdh::parse(data, (size_t)n, p)) return fail(e);
+    Header& hd = p.hd;
+    if (width) *width = hd.width;
+    if (height) *height = hd.height;
+    if ((int64_t)hd.width * hd.height * 3 > capacity) {
+        wt::set_error("wd_jpeg_decode_rgb_u8: output needs %lld bytes, capacity %lld", (long long)hd.width * hd.height * 3, (long long)capacity);
+        return WT_ERR_CAPACITY;
+    }
+    const Layout L = jdh::layout_for((size_t)n, p.scan_pos, p.expected_segments);
+    size_t planes_bytes = 0;
+    for (int c = 0; c < hd.ncomp; ++c) planes_bytes = (size_t)hd.plane_off[c] + wt::align_up((size_t)hd.plane_pitch[c] * hd.plane_rows[c]);
+    size_t woff = 0;
+    auto take = [&](size_t b) { const size_t o = woff; woff += wt::align_up(b); return o; };
+    const size_t o_nblk = take((size_t)L.max_sub * 4), o_base = take((size_t)L.max_sub * 4), o_flags = take(64);
+    const size_t o_coef = take((size_t)hd.total_blocks * 128), o_planes = take(planes_bytes);
+    Ctx* ctx = acquire();
+    Release rel{ctx};
+    WT_TRY(grow(*ctx, L.total, woff));
+    if (const char* e = jdh::unstuff(data, (size_t)n, p.scan_pos, L, p.expected_segments, ctx->host, hd)) return fail(e);
+    memcpy(ctx->host + L.header, &hd, sizeof(Header));
+    memcpy(ctx->host + L.luts, p.luts, sizeof(p.luts));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t used = L.stream + (size_t)hd.nsub * 128 + 16;
+    WT_HIP(hipMemcpyAsync(ctx->dev, ctx->host, used, hipMemcpyHostToDevice, st));
+    WT_HIP(hipMemsetAsync(ctx->work, 0, o_coef + (size_t)hd.total_blocks * 128, st));       // nblk, base, flags, coefficients
+    Dev d;
+    d.hd = reinterpret_cast<const Header*>(ctx->dev + L.header);
+    d.luts = reinterpret_cast<const HuffLut*>(ctx->dev + L.luts);
+    d.seg_first_sub = reinterpret_cast<const uint32_t*>(ctx->dev + L.seg_first_sub);
+    d.seg_end_bit = reinterpret_cast<const uint32_t*>(ctx->dev + L.seg_end_bit);
+    d.sub_seg = reinterpret_cast<const int32_t*>(ctx->dev + L.sub_seg);
+    d.start = reinterpret_cast<State*>(ctx->dev + L.start);
+    d.exit = reinterpret_cast<State*>(ctx->dev + L.exit);
+    d.stream = reinterpret_cast<const uint32_t*>(ctx->dev + L.stream);
+    d.nblk = reinterpret_cast<int32_t*>(ctx->work + o_nblk);
+    d.base = reinterpret_cast<int32_t*>(ctx->work + o_base);
+    d.flags = reinterpret_cast<int32_t*>(ctx->work + o_flags);
+    d.coef = reinterpret_cast<int16_t*>(ctx->work + o_coef);
+    d.planes = ctx->work + o_planes;
+    d.nsub = hd.nsub;
+    d.stream_words = hd.nsub * jd::SUB_WORDS + 4;
+    const unsigned sync_grid = (unsigned)((hd.nsub + kSyncThreads - 1) / kSyncThreads);
+    int rounds = 0;
+    auto tail = [&]() -> int {
+        hipLaunchKernelGGL(jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, d);
+        hipLaunchKernelGGL(jpeg_write_kernel, dim3(sync_grid), dim3(kSyncThreads), 0, st, d);
+        hipLaunchKernelGGL(jpeg_dc_kernel, dim3((unsigned)hd.ncomp), dim3(1024), 0, st, d);
+        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((hd.total_blocks + 31) / 32)), dim3(256), 0, st, d);
+        const int fh = hd.ncomp == 3 ? hd.hmax / hd.comp_h[1] : 1, fv = hd.ncomp == 3 ? hd.vmax / hd.comp_v[1] : 1;
+        const dim3 grid((unsigned)(((hd.width + fh - 1) / fh + 63) / 64), (unsigned)(((hd.height + fv - 1) / fv + 3) / 4));
+        if (hd.ncomp == 1) hipLaunchKernelGGL(jpeg_color_kernel<3>, grid, dim3(256), 0, st, d, rgb);
+        else if (fh == 1) hipLaunchKernelGGL(jpeg_color_kernel<0>, grid, dim3(256), 0, st, d, rgb);
+        else if (fv == 1) hipLaunchKernelGGL(jpeg_color_kernel<1>, grid, dim3(256), 0, st, d, rgb);
+        else hipLaunchKernelGGL(jpeg_color_kernel<2>, grid, dim3(256), 0, st, d, rgb);
+        WT_HIP(hipGetLastError());
+        WT_HIP(hipMemcpyAsync(ctx->host_flags, d.flags, 8, hipMemcpyDeviceToHost, st));
+        WT_HIP(hipStreamSynchronize(st));
+        return WT_OK;
+    };
+    for (; rounds < 3; ++rounds) hipLaunchKernelGGL(jpeg_sync_kernel, dim3(sync_grid), dim3(kSyncThreads), 0, st, d);
+    WT_TRY(tail());
+    while (ctx->host_flags[0]) {                      // chain not settled yet: more rounds, then the tail again
+        if (rounds > hd.nsub + 3) return fail("internal: subsequence chain did not settle");
+        WT_HIP(hipMemsetAsync(d.flags, 0, 8, st));
+        WT_HIP(hipMemsetAsync(d.coef, 0, (size_t)hd.total_blocks * 128, st));
+        for (int k = 0; k < 4; ++k, ++rounds) hipLaunchKernelGGL(jpeg_sync_kernel, dim3(sync_grid), dim3(kSyncThreads), 0, st, d);
+        WT_TRY(tail());
+    }
+    if (sync_rounds) *sync_rounds = rounds;
+    if (ctx->host_flags[1]) return fail("entropy-coded data ends before the last block (truncated or corrupt file)");
+    return WT_OK;
+}

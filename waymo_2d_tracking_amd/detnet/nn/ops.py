@@ -428,6 +428,31 @@ def preprocess(x, scale=1.0, hflip=False, vflip=False, swap_rb=True, mean=None, 
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# image decode
+def jpeg_info(data):
+    """(width, height, components, h_samp, v_samp, restart_interval) of a baseline JPEG (host-only header parse)."""
+    buf = bytes(data)
+    o = [C.c_int32(0) for _ in range(6)]
+    _lib.check(_lib.lib().wd_jpeg_info(buf, C.c_int64(len(buf)), *[C.byref(v) for v in o]), 'wd_jpeg_info')
+    return tuple(v.value for v in o)
+
+
+def jpeg_decode(data, device=None, return_rounds=False):
+    """bytes of a JPEG file -> (H, W, 3) uint8 RGB tensor on the GPU, bit-exact with
+    `PIL.Image.open(...).convert('RGB')` (the reference's decode, detnet/inference.py:170).  Huffman decoding, inverse DCT,
+    chroma upsampling and colour conversion all run in HIP kernels (csrc/jpeg_decode.hip); no host decoder is involved.
+    Unsupported flavours (progressive, CMYK, ...) raise WaymoTrackError."""
+    buf = bytes(data)
+    w, h = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.lib().wd_jpeg_info(buf, C.c_int64(len(buf)), C.byref(w), C.byref(h), None, None, None, None), 'wd_jpeg_info')
+    out = torch.empty((h.value, w.value, 3), dtype=torch.uint8, device=device or 'cuda')
+    rounds = C.c_int32(0)
+    _lib.check(_lib.lib().wd_jpeg_decode_rgb_u8(buf, C.c_int64(len(buf)), _p(out), C.c_int64(out.numel()), C.byref(w), C.byref(h),
+                                                C.byref(rounds), _stream()), 'wd_jpeg_decode_rgb_u8')
+    return (out, rounds.value) if return_rounds else out
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # training (fwd + bwd): autograd wrappers around the forward kernels and the backward kernels of det_backward.hip
 def deform_im2col(x, offset, stride=1, pad=1, groups=1):
     """col (groups, P, 9, C/groups) float32, P = N*Ho*Wo (detectron2 deformable_im2col; group-major column layout)."""
