@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--stage', default=os.environ.get('WT_BENCH_STAGE', 'e2e'),
-                    choices=['e2e', 'detect', 'track', 'ensemble', 'train'])
+                    choices=['e2e', 'detect', 'track', 'ensemble', 'train', 'decode'])
     ap.add_argument('--segments', type=int, default=8, help='track stage: segments (x5 cameras x198 frames) per GPU')
     ap.add_argument('--images', type=int, default=990, help='ensemble stage: images per GPU')
     ap.add_argument('--k-inputs', type=int, default=13)
@@ -385,6 +385,92 @@ def cpu_baseline_train(det, height=160, width=224):
                        '886x1280 has %.1fx the pixels' % (width, height, dt, ratio), full_res_equivalent=1.0 / (dt * ratio))
 
 
+def synthetic_camera_jpegs(seed):
+    """One frame set of a Waymo segment as JPEG files in memory: 3 x 1920x1280 (front cameras) + 2 x 1920x886 (side cameras),
+    4:2:0, quality 90, photo-like content (low-frequency structure + sensor noise) - encoded with PIL."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    out = []
+    for cam, (h, w) in enumerate([(1280, 1920)] * 3 + [(886, 1920)] * 2):
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = 128 + 100 * np.sin(xx[..., None] / (5.0 + cam) + np.arange(3)) * np.cos(yy[..., None] / (7.0 + cam))
+        img = np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, 'JPEG', quality=90, subsampling=2)
+        out.append(buf.getvalue())
+    return out
+
+
+def stage_decode(args, world, rank):
+    """JPEG decode of the camera frames in front of the detector (the reference: PIL in its dataset
+    workers).  A step = --frames-per-step / 5 frame sets x 5 cameras, file bytes on the host -> (H, W, 3) uint8 RGB in HBM, through the
+    loader's scheme (4 threads, one stream each).  The compressed bytes cross PCIe inside the timed region (1.1 MB per
+    front frame - they are the input of the op)."""
+    import io
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    files = synthetic_camera_jpegs(3000 + rank)
+    frames = max(1, args.frames_per_step // 5)
+    batch = files * frames
+    pool = ThreadPoolExecutor(4)
+    streams = {}
+
+    def one(data):
+        import threading
+        st = streams.setdefault(threading.get_ident(), torch.cuda.Stream())
+        with torch.cuda.stream(st):
+            return ops.jpeg_decode(data)
+
+    def step():
+        return list(pool.map(one, batch))
+    steps = args.steps or 20
+    warmup = args.warmup if args.warmup is not None else 3
+    dt, ev_ms = timed_steps(world, step, steps, warmup)
+    outs = step()
+    in_bytes = float(sum(len(b) for b in batch))
+    out_bytes = float(sum(o.numel() for o in outs))
+    alg = in_bytes + out_bytes                          # compressed bytes in, RGB bytes out (intermediate coefficients are the decoder's own)
+    res = dict(value=len(batch) * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps,
+               workload='JPEG decode of %d frame sets x 5 cameras (3 x 1920x1280 + 2 x 1920x886, 4:2:0, q90) per GPU and step, '
+                        'file bytes on the host -> RGB u8 in HBM' % frames,
+               dtype='u8',
+               roofline=dict(bound='latency', kernel='jpeg_sync_kernel', achieved=alg / (dt / steps) / 1e9, peak=8000.0, unit='GB/s',
+                             frac=alg / (dt / steps) / 1e9 / 8000.0, traffic=None,
+                             note='Huffman decoding is a serial dependency per 1024-bit subsequence: the synchronisation rounds '
+                                  '(one wave per SIMD, ~1500 cycles per symbol) set the time, not HBM; algorithmic bytes = compressed '
+                                  'bytes in + RGB bytes out'),
+               extra=dict(compressed_mb_per_step=in_bytes / 1e6, rgb_mb_per_step=out_bytes / 1e6, loader_threads=4))
+    if rank == 0 and not args.no_verify:
+        from PIL import Image
+        ok = all(np.array_equal(o.cpu().numpy(), np.asarray(Image.open(io.BytesIO(b)).convert('RGB'))) for o, b in zip(outs[:5], batch[:5]))
+        res['verified'] = dict(ok=bool(ok), against="PIL Image.open(...).convert('RGB') - the reference's decoder - on the 5 distinct files, bit for bit")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from PIL import Image
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 5.0:
+            np.asarray(Image.open(io.BytesIO(batch[n % len(batch)])).convert('RGB'))
+            n += 1
+        single = n / (time.perf_counter() - t0)
+        cores = min(os.cpu_count() or 1, 64)
+        per = max(5, int(single * 5.0))
+
+        def work(k):
+            for j in range(per):
+                np.asarray(Image.open(io.BytesIO(batch[(k + j) % len(batch)])).convert('RGB'))      # libjpeg releases the GIL
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(work, range(cores)))
+        multi = cores * per / (time.perf_counter() - t0)
+        res['cpu_baseline'] = dict(value=multi, unit='frames/s', cores=cores, kind='reference', single_thread=single,
+                                   sample="PIL (libjpeg-turbo %s) Image.open().convert('RGB') on the same files: 5 s on one thread, "
+                                          'then %d threads x %d decodes' % (__import__('PIL.features', fromlist=['version']).version('libjpeg_turbo'), cores, per))
+    pool.shutdown()
+    return res, steps, warmup
+
+
 def main():
     args = parse_args()
     launch_if_needed(args)         # no GPU call before this line
@@ -398,6 +484,9 @@ def main():
     elif args.stage == 'ensemble':
         res, steps, warmup = stage_ensemble(args, world, rank)
         metric = 'soft-NMS ensemble images/sec'
+    elif args.stage == 'decode':
+        res, steps, warmup = stage_decode(args, world, rank)
+        metric = 'JPEG decode frames/sec (camera frames in front of the detector)'
     elif args.stage == 'train':
         from waymo_2d_tracking_amd import bench_e2e
         res, steps, warmup = bench_e2e.run_train(args, world, rank, timed_steps)

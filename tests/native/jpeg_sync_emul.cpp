@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE: runs the GPU JPEG decoder's entropy stage on the CPU, thread by thread - the same jd::run,
 // the same staging blob (jpeg_host.h) and the same round structure as jpeg_sync_kernel / jpeg_scan_kernel /
-// jpeg_write_kernel / jpeg_dc_kernel in csrc/jpeg_decode.hip - so that the synchronisation scheme can be checked against
+// jpeg_write_kernel in csrc/jpeg_decode.hip - so that the synchronisation scheme can be checked against
 // the sequential restatement (oracle/jpeg_ref.py) without a GPU.  Not part of libwaymotrack.so.
 //   extern "C" int jpeg_emul_coefficients(data, n, group, coef_out, capacity_blocks, &rounds, &total_blocks, err, errlen)
 // `group` = threads per emulated workgroup (256 on the GPU); coefficients come back in scan order (block, 64) int16.
@@ -33,10 +33,11 @@ extern "C" int jpeg_emul_coefficients(const uint8_t* data, long n, int group, in
     std::vector<uint32_t> words((size_t)nsub * SUB_WORDS + 4);
     for (size_t w = 0; w < words.size(); ++w) {
         uint32_t v = 0;
-        for (int k = 0; k < 4; ++k) { const size_t bi = w * 4 + k; v = (v << 8) | (bi < (size_t)nsub * 128 + 16 ? bytes[bi] : 0xFF); }
+        for (int k = 0; k < 4; ++k) { const size_t bi = w * 4 + k; v = (v << 8) | (bi < (size_t)nsub * SUB_BYTES + 16 ? bytes[bi] : 0xFF); }
         words[w] = v;
     }
-    std::vector<int> nblk(nsub, 0), base(nsub, 0);
+    std::vector<Counts> cnt(nsub, Counts{0, {0, 0, 0}}), base(nsub, Counts{0, {0, 0, 0}});
+    const Sel sel = make_sel(&hd);
     auto bound_of = [&](int i) { const uint32_t b = (uint32_t)(i + 1) * SUB_BITS, e = seg_end[sub_seg[i]]; return b < e ? b : e; };
     auto is_first = [&](int i) { return seg_first[sub_seg[i]] == (uint32_t)i; };
     int rounds = 0;
@@ -55,9 +56,7 @@ extern "C" int jpeg_emul_coefficients(const uint8_t* data, long n, int group, in
                     else want = i == g0 ? before[i - 1] : snap[i - 1 - g0];
                     if (same(want, start[i])) continue;
                     start[i] = want;
-                    int nb = 0;
-                    const State e = run<false>(want, bound_of(i), seg_end[sub_seg[i]], words.data(), 0u, p.luts, &hd, nb, nullptr, 0, 0);
-                    nblk[i] = nb;
+                    const State e = run<false>(want, bound_of(i), seg_end[sub_seg[i]], words.data(), 0u, p.luts, sel, cnt[i], nullptr, 0, 0, nullptr);
                     if (!same(e, exits[i])) { exits[i] = e; changed = true; }
                 }
                 if (!changed) break;
@@ -76,32 +75,26 @@ extern "C" int jpeg_emul_coefficients(const uint8_t* data, long n, int group, in
     }
     *rounds_out = rounds;
     int shortfall = 0;
-    for (int s = 0; s < hd.nseg; ++s) {
-        int acc = 0;
+    for (int s = 0; s < hd.nseg; ++s) {                                   // jpeg_scan_kernel: running values per segment
+        Counts acc{0, {0, 0, 0}};
         const int b0 = s * hd.ri * hd.bpm;
-        for (uint32_t i = seg_first[s]; i < seg_first[s + 1]; ++i) { base[i] = b0 + acc; acc += nblk[i]; }
+        for (uint32_t i = seg_first[s]; i < seg_first[s + 1]; ++i) {
+            base[i] = acc;
+            base[i].n += b0;
+            acc.n += cnt[i].n;
+            for (int c = 0; c < 3; ++c) acc.dc[c] += cnt[i].dc[c];
+        }
         int expect = hd.total_blocks - b0;
         expect = expect < hd.ri * hd.bpm ? expect : hd.ri * hd.bpm;
-        shortfall |= acc < expect;
+        shortfall |= acc.n < expect;
     }
     std::fill(coef, coef + (size_t)hd.total_blocks * 64, (int16_t)0);
-    for (int i = 0; i < nsub; ++i) {
+    for (int i = 0; i < nsub; ++i) {                                      // jpeg_write_kernel
         const int s = sub_seg[i];
         int block_end = (s + 1) * hd.ri * hd.bpm;
         block_end = block_end < hd.total_blocks ? block_end : hd.total_blocks;
-        int nb = 0;
-        (void)run<true>(start[i], bound_of(i), seg_end[s], words.data(), 0u, p.luts, &hd, nb, coef, base[i], block_end);
-    }
-    for (int c = 0; c < hd.ncomp; ++c) {                                  // DC prediction
-        const int nbk = hd.comp_nblk[c], len = hd.mx * hd.my * nbk;
-        int pred = 0;
-        for (int t = 0; t < len; ++t) {
-            const int mcu = t / nbk, j = t % nbk;
-            if (j == 0 && mcu % hd.ri == 0) pred = 0;
-            int16_t& v = coef[(size_t)(mcu * hd.bpm + hd.comp_off[c] + j) * 64];
-            pred += v;
-            v = (int16_t)pred;
-        }
+        Counts c;
+        (void)run<true>(start[i], bound_of(i), seg_end[s], words.data(), 0u, p.luts, sel, c, coef, base[i].n, block_end, base[i].dc);
     }
     if (shortfall) { snprintf(err, errlen, "segment came up short"); return 4; }
     return 0;

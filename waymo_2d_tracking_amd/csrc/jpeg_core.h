@@ -24,16 +24,23 @@
 
 namespace jd {
 
-constexpr int SUB_BITS = 1024;                     // bits per subsequence (= 128 bytes = 32 words)
+#ifndef JD_SUB_BITS
+#define JD_SUB_BITS 1024
+#endif
+constexpr int SUB_BITS = JD_SUB_BITS;              // bits per subsequence (1024 = 128 bytes = 32 words)
+constexpr int SUB_BYTES = SUB_BITS / 8;
 constexpr int SUB_WORDS = SUB_BITS / 32;
 constexpr int MAX_BPM = 10;                        // blocks per MCU (T.81 B.2.3)
 constexpr uint32_t NO_STATE = 0xFFFFFFFFu;
 
-// decoder table of one Huffman table: 8-bit first-level lookup, canonical search for the longer codes (jdhuff.c)
-struct HuffLut {
+// decoder table of one Huffman table.  Codes of <= 8 bits: one lookup with the next 8 bits.  Longer codes: canonical
+// codes are ordered, so with limit[l] = (first code value after the codes of length l) left-justified to 16 bits - a
+// non-decreasing sequence - the length of the code at the top of a 16-bit window w is 9 + #{l in 9..16 : w >= limit[l]}:
+// eight independent compares instead of jdhuff.c's bit-by-bit maxcode loop (a chain of dependent reads on a GPU).
+struct alignas(16) HuffLut {
     uint16_t fast[256];                            // (length << 8) | symbol for codes of <= 8 bits, 0 = longer / invalid
-    int32_t maxcode[18];                           // largest code of length l (-1 if none); [17] = sentinel
-    int32_t valoff[18];                            // vals index of the first code of length l minus that code
+    uint32_t limit[8];                             // lengths 9..16
+    uint16_t valoff[8];                            // lengths 9..16: (vals index of the first code of length l - that code) mod 2^16
     uint8_t vals[256];
 };
 
@@ -65,53 +72,102 @@ struct State {
 };
 JD_HD bool same(const State& a, const State& b) { return a.p == b.p && a.bk == b.bk; }
 
-// 32 bits of the stream starting at bit p; `words` holds the stream as big-endian 32-bit words relative to word `w0`
-template <class WordPtr>
-JD_HD uint32_t peek32(WordPtr words, uint32_t w0, uint32_t p) {
-    const uint32_t wi = (p >> 5) - w0, sh = p & 31;
-    const uint64_t two = ((uint64_t)words[wi] << 32) | words[wi + 1];
-    return (uint32_t)((two << sh) >> 32);
-}
-
 // one Huffman symbol from the top of `win`; returns the code length (0 = no code: only in padding or out of step)
 template <class LutPtr>
 JD_HD int symbol(LutPtr lut, uint32_t win, int& sym) {
     const uint32_t f = lut->fast[win >> 24];
-    if (f) { sym = (int)(f & 255); return (int)(f >> 8); }
+    const uint32_t w16 = win >> 16;
+    uint32_t vo[8];
     int l = 9;
-    int32_t code = (int32_t)(win >> 23);
-    while (l <= 16 && code > lut->maxcode[l]) { ++l; code = (int32_t)(win >> (32 - l)); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        l += w16 >= lut->limit[j] ? 1 : 0;
+        vo[j] = lut->valoff[j];
+    }
+    if (f) { sym = (int)(f & 255); return (int)(f >> 8); }
     if (l > 16) return 0;
-    sym = lut->vals[(code + lut->valoff[l]) & 255];
+    uint32_t v = vo[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) v = l - 9 == j ? vo[j] : v;
+    sym = lut->vals[((win >> (32 - l)) + v) & 255];
     return l;
 }
 
 JD_HD int extend(uint32_t r, int s) { return (int)r < (1 << (s - 1)) ? (int)r - (1 << s) + 1 : (int)r; }
 
+// table selection without memory reads: bit b of dc / ac = Huffman table of block-in-MCU b, 2 bits per block = component
+struct Sel {
+    uint32_t dc, ac, comp;
+    int bpm;
+};
+template <class HeaderPtr>
+JD_HD Sel make_sel(HeaderPtr hd) {
+    Sel s;
+    s.dc = s.ac = s.comp = 0;
+    s.bpm = hd->bpm;
+    for (int b = 0; b < hd->bpm; ++b) {
+        const int c = hd->blk_comp[b];
+        s.dc |= (uint32_t)hd->comp_dc[c] << b;
+        s.ac |= (uint32_t)hd->comp_ac[c] << b;
+        s.comp |= (uint32_t)c << (2 * b);
+    }
+    return s;
+}
+
+// what a subsequence contributes to the sequential decoder's running values: blocks completed, DC differences per component
+struct Counts {
+    int32_t n, dc[3];
+};
+
 // Decode from `st` while the position is inside [.., bound): bound = end of the thread's subsequence or of its restart
 // segment, whichever comes first; a symbol that does not fit before `seg_end` ends the segment (padding bits).
-// Returns the exit state; `nblk` counts the blocks completed.  WRITE: coefficients (DC still as difference) go to
-// coef[(block0 + completed) * 64 + natural position] as long as the block index stays below block_end.
-template <bool WRITE, class WordPtr, class LutPtr, class HeaderPtr>
-JD_HD State run(State st, uint32_t bound, uint32_t seg_end, WordPtr words, uint32_t w0, LutPtr luts, HeaderPtr hd,
-                int& nblk, int16_t* __restrict__ coef, int block0, int block_end) {
+// Returns the exit state; `cnt` = blocks completed and the sum of the DC differences decoded, per component.
+// WRITE: coefficients go to coef[(block0 + completed) * 64 + natural position] as long as the block index stays below
+// block_end, DC as the running prediction that starts at pred0[component].
+// The bit window lives in registers (64 bits, refilled one word at a time with the next word already in flight): one
+// dependent LDS access per symbol - the table lookup.
+template <bool WRITE, class WordPtr, class LutPtr>
+JD_HD State run(State st, uint32_t bound, uint32_t seg_end, WordPtr words, uint32_t w0, LutPtr luts, const Sel sel,
+                Counts& cnt, int16_t* __restrict__ coef, int block0, int block_end, const int32_t* pred0) {
     uint32_t p = st.p;
     int blk = (int)(st.bk >> 8), k = (int)(st.bk & 255);
-    const int bpm = hd->bpm;
-    int n = 0;
-    int comp = hd->blk_comp[blk];
+    int n = 0, d0 = 0, d1 = 0, d2 = 0;
+    int pr0 = 0, pr1 = 0, pr2 = 0;
+    if (WRITE) { pr0 = pred0[0]; pr1 = pred0[1]; pr2 = pred0[2]; }
+    uint32_t wi = (p >> 5) - w0;
+    uint32_t used = p & 31;
+    uint32_t hi = words[wi], lo = words[wi + 1], ahead = words[wi + 2];      // 64-bit window + the next word in flight
     while (p < bound) {
-        const uint32_t win = peek32(words, w0, p);
+        const uint32_t win = used ? (hi << used) | (lo >> (32 - used)) : hi;
         int sym = 0;
-        const int len = symbol(luts + (k == 0 ? hd->comp_dc[comp] : 2 + hd->comp_ac[comp]), win, sym);
+        const uint32_t tsel = k == 0 ? ((sel.dc >> blk) & 1u) : 2u + ((sel.ac >> blk) & 1u);
+        const int len = symbol(luts + tsel, win, sym);
         if (len == 0) { p = bound; break; }                                 // no such code: padding, or an out-of-step thread
         const int s = k == 0 ? (sym > 16 ? 16 : sym) : (sym & 15);
         if (p + (uint32_t)(len + s) > seg_end) { p = seg_end; break; }
-        const uint32_t extra = s ? (uint32_t)(((uint64_t)win << len) >> (32 - s)) & ((1u << s) - 1u) : 0u;
+        const uint32_t extra = s ? (win << len) >> (32 - s) : 0u;          // len + s <= 32
         p += (uint32_t)(len + s);
+        used += (uint32_t)(len + s);
+        if (used >= 32) {
+            used -= 32;
+            ++wi;
+            hi = lo;
+            lo = ahead;
+            ahead = words[wi + 2];
+        }
         bool done = false;
         if (k == 0) {
-            if (WRITE && block0 + n < block_end) coef[(size_t)(block0 + n) * 64] = (int16_t)(s ? extend(extra, s) : 0);
+            const int diff = s ? extend(extra, s) : 0;
+            const uint32_t comp = (sel.comp >> (2 * blk)) & 3u;
+            d0 += comp == 0 ? diff : 0;
+            d1 += comp == 1 ? diff : 0;
+            d2 += comp == 2 ? diff : 0;
+            if (WRITE) {
+                pr0 += comp == 0 ? diff : 0;
+                pr1 += comp == 1 ? diff : 0;
+                pr2 += comp == 2 ? diff : 0;
+                if (block0 + n < block_end) coef[(size_t)(block0 + n) * 64] = (int16_t)(comp == 0 ? pr0 : comp == 1 ? pr1 : pr2);
+            }
             k = 1;
         } else {
             const int r = sym >> 4;
@@ -128,11 +184,10 @@ JD_HD State run(State st, uint32_t bound, uint32_t seg_end, WordPtr words, uint3
         if (done || k >= 64) {
             k = 0;
             ++n;
-            blk = blk + 1 == bpm ? 0 : blk + 1;
-            comp = hd->blk_comp[blk];
+            blk = blk + 1 == sel.bpm ? 0 : blk + 1;
         }
     }
-    nblk = n;
+    cnt.n = n; cnt.dc[0] = d0; cnt.dc[1] = d1; cnt.dc[2] = d2;
     State out;
     out.p = p;
     out.bk = ((uint32_t)blk << 8) | (uint32_t)k;

@@ -2,9 +2,8 @@
 //   host   : marker parse, Huffman / quantisation tables, byte unstuffing into restart segments (a memchr pass), one
 //            pinned staging blob -> ONE hipMemcpyAsync
 //   device : jpeg_sync_kernel (x3)  - subsequence synchronisation, bitstream + tables in LDS
-//            jpeg_scan_kernel       - chain check + first block index of every subsequence (segmented scan)
-//            jpeg_write_kernel      - final decode pass, coefficients (int16, natural order) to HBM
-//            jpeg_dc_kernel         - DC prediction = segmented prefix sum per component
+//            jpeg_scan_kernel       - chain check + first block index / DC predictions of every subsequence (segmented scan)
+//            jpeg_write_kernel      - final decode pass, coefficients (int16, natural order, DC resolved) to HBM
 //            jpeg_idct_kernel       - dequantise + jidctint.c islow, 8 threads per block, planes in u8
 //            jpeg_color_kernel      - fancy h2v1 / h2v2 upsampling + YCbCr -> RGB, (H, W, 3) u8 out
 // The call returns after its stream has drained (it has to read the "chain settled" flag); when the flag is not set
@@ -25,7 +24,7 @@ using jdh::Layout;
 using jdh::Parsed;
 
 constexpr int kSyncThreads = 256;
-constexpr int kLdsWords = kSyncThreads * jd::SUB_WORDS + 2;
+constexpr int kLdsWords = kSyncThreads * jd::SUB_WORDS + 4;
 
 // ---------------------------------------------------------------------------------------------------------------- host
 int fail(const char* msg) {
@@ -43,8 +42,8 @@ struct Dev {                         // device pointers into the blob + work buf
     State* start;
     State* exit;
     const uint32_t* stream;          // bytes as stored (big-endian bit order): words are byte-swapped on load
-    int32_t* nblk;                   // blocks completed per subsequence
-    int32_t* base;                   // first block index per subsequence
+    int4* cnt;                       // per subsequence: blocks completed, DC differences summed per component
+    int4* base;                      // per subsequence: first block index, DC predictions at its start
     int16_t* coef;
     uint8_t* planes;
     int32_t* flags;                  // [0] chain not settled, [1] a segment came up short
@@ -66,18 +65,17 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
     __shared__ uint32_t words[kLdsWords];
     __shared__ HuffLut luts[4];
     __shared__ State exits[kSyncThreads];
-    __shared__ Header hd;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kSyncThreads + tid;
     const bool valid = i < d.nsub;
     stage(d, words, luts);
-    for (int j = tid; j < (int)(sizeof(Header) / 4); j += kSyncThreads) reinterpret_cast<uint32_t*>(&hd)[j] = reinterpret_cast<const uint32_t*>(d.hd)[j];
+    const jd::Sel sel = jd::make_sel(d.hd);
     const uint32_t w0 = blockIdx.x * (uint32_t)(kSyncThreads * jd::SUB_WORDS);
     int seg = 0;
     bool first = false;
     uint32_t seg_end = 0, bound = 0;
     State s_cur{jd::NO_STATE, jd::NO_STATE}, e_cur{0, 0}, from_prev{0, 0};
-    int n_cur = 0;
+    jd::Counts c_cur{0, {0, 0, 0}};
     if (valid) {
         seg = d.sub_seg[i];
         first = d.seg_first_sub[seg] == (uint32_t)i;
@@ -86,7 +84,8 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
         bound = bound < seg_end ? bound : seg_end;
         s_cur = d.start[i];
         e_cur = d.exit[i];
-        n_cur = d.nblk[i];
+        const int4 c = d.cnt[i];
+        c_cur.n = c.x; c_cur.dc[0] = c.y; c_cur.dc[1] = c.z; c_cur.dc[2] = c.w;
         if (tid == 0 && !first) from_prev = d.exit[i - 1];
     }
     exits[tid] = e_cur;
@@ -94,157 +93,127 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
     for (;;) {
         State want;
         if (first) { want.p = (uint32_t)i * jd::SUB_BITS; want.bk = 0; }
-        else want = tid == 0 ? from_prev : exits[tid - 1];
+        else {
+            const State left = exits[tid > 0 ? tid - 1 : 0];
+            want.p = tid == 0 ? from_prev.p : left.p;
+            want.bk = tid == 0 ? from_prev.bk : left.bk;
+        }
         __syncthreads();
         int changed = 0;
         if (valid && !jd::same(want, s_cur)) {
             s_cur = want;
-            int n = 0;
-            const State e = jd::run<false>(s_cur, bound, seg_end, words, w0, luts, &hd, n, nullptr, 0, 0);
-            n_cur = n;
+            const State e = jd::run<false>(s_cur, bound, seg_end, words, w0, luts, sel, c_cur, nullptr, 0, 0, nullptr);
             if (!jd::same(e, e_cur)) { e_cur = e; exits[tid] = e; changed = 1; }
         }
         if (!__syncthreads_or(changed)) break;
     }
-    if (valid) { d.start[i] = s_cur; d.exit[i] = e_cur; d.nblk[i] = n_cur; }
+    if (valid) { d.start[i] = s_cur; d.exit[i] = e_cur; d.cnt[i] = make_int4(c_cur.n, c_cur.dc[0], c_cur.dc[1], c_cur.dc[2]); }
 }
 
-// one workgroup: is every start state the exit state of its predecessor (or the known segment start)?  first block index
-// of every subsequence = blocks of its segment before it (segmented exclusive scan over nblk)
+// one workgroup: is every start state the exit state of its predecessor (or the known segment start)?  Running values of
+// the sequential decoder at the start of every subsequence = segmented exclusive scan over (blocks, DC differences)
 __global__ __launch_bounds__(1024) void jpeg_scan_kernel(Dev d) {
-    __shared__ int vals[1024];
+    constexpr int ITEMS = 4;
+    __shared__ int4 vals[1024];
     __shared__ int flgs[1024];
-    __shared__ int carry_s;
+    __shared__ int4 carry_s;
     const int tid = threadIdx.x;
     const Header* hd = d.hd;
     const int bpm = hd->bpm, ri = hd->ri, total = hd->total_blocks;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) carry_s = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    auto add = [](const int4 a, const int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
     int bad = 0, shortfall = 0;
-    for (int c0 = 0; c0 < d.nsub; c0 += 1024) {
-        const int i = c0 + tid;
-        int n = 0, f = 0, seg = 0;
-        if (i < d.nsub) {
-            seg = d.sub_seg[i];
-            f = d.seg_first_sub[seg] == (uint32_t)i;
-            n = d.nblk[i];
-            const State s = d.start[i];
-            State want;
-            if (f) { want.p = (uint32_t)i * jd::SUB_BITS; want.bk = 0; } else want = d.exit[i - 1];
-            bad |= !jd::same(s, want);
+    for (int c0 = 0; c0 < d.nsub; c0 += 1024 * ITEMS) {
+        int4 v[ITEMS];
+        int segs[ITEMS];
+        int4 run = make_int4(0, 0, 0, 0);
+        int any = 0, firsts = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int i = c0 + tid * ITEMS + j;
+            int4 c = make_int4(0, 0, 0, 0);
+            int f = 0;
+            segs[j] = 0;
+            if (i < d.nsub) {
+                segs[j] = d.sub_seg[i];
+                f = d.seg_first_sub[segs[j]] == (uint32_t)i;
+                c = d.cnt[i];
+                const State s = d.start[i];
+                State want;
+                if (f) { want.p = (uint32_t)i * jd::SUB_BITS; want.bk = 0; } else want = d.exit[i - 1];
+                bad |= !jd::same(s, want);
+            }
+            run = f ? c : add(run, c);
+            any |= f;
+            firsts |= f << j;
+            v[j] = run;                               // inclusive within the thread since its last segment start
         }
+        vals[tid] = run;
+        flgs[tid] = any;
         __syncthreads();
-        vals[tid] = n;
-        flgs[tid] = f;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {                         // inclusive segmented scan
-            int v = vals[tid], g = flgs[tid];
-            if (tid >= off && !g) { v += vals[tid - off]; g = flgs[tid - off]; }
+        for (int off = 1; off < 1024; off <<= 1) {   // inclusive segmented scan over the thread totals
+            int4 a = vals[tid];
+            int g = flgs[tid];
+            if (tid >= off && !g) { a = add(a, vals[tid - off]); g = flgs[tid - off]; }
             __syncthreads();
-            vals[tid] = v;
+            vals[tid] = a;
             flgs[tid] = g;
             __syncthreads();
         }
-        const int incl = vals[tid] + (flgs[tid] ? 0 : carry_s);            // blocks of the segment up to and including i
-        if (i < d.nsub) {
-            const int seg_block0 = seg * ri * bpm;
-            d.base[i] = seg_block0 + incl - n;
-            if (d.seg_first_sub[seg + 1] == (uint32_t)(i + 1)) {             // last subsequence of its segment
+        const int4 chunk = carry_s;
+        int4 carry = chunk;                           // running values in front of this thread's first item
+        if (tid > 0) carry = flgs[tid - 1] ? vals[tid - 1] : add(vals[tid - 1], chunk);
+        const int4 last = flgs[1023] ? vals[1023] : add(vals[1023], chunk);
+        bool seen = false;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int i = c0 + tid * ITEMS + j;
+            if (i >= d.nsub) continue;
+            seen |= (firsts >> j) & 1;
+            const int4 incl = seen ? v[j] : add(v[j], carry);
+            const int4 c = d.cnt[i];
+            const int seg_block0 = segs[j] * ri * bpm;
+            d.base[i] = make_int4(seg_block0 + incl.x - c.x, incl.y - c.y, incl.z - c.z, incl.w - c.w);
+            if (d.seg_first_sub[segs[j] + 1] == (uint32_t)(i + 1)) {            // last subsequence of its segment
                 int expect = total - seg_block0;
                 expect = expect < ri * bpm ? expect : ri * bpm;
-                shortfall |= incl < expect;
+                shortfall |= incl.x < expect;
             }
         }
         __syncthreads();
-        if (tid == 1023) carry_s = incl;
+        if (tid == 0) carry_s = last;
         __syncthreads();
     }
     if (bad) atomicOr(&d.flags[0], 1);
     if (shortfall) atomicOr(&d.flags[1], 1);
 }
 
+// final pass: decode from the settled start states and write the coefficients, DC prediction already resolved
 __global__ __launch_bounds__(kSyncThreads) void jpeg_write_kernel(Dev d) {
     __shared__ uint32_t words[kLdsWords];
     __shared__ HuffLut luts[4];
-    __shared__ Header hd;
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kSyncThreads + tid;
     stage(d, words, luts);
-    for (int j = tid; j < (int)(sizeof(Header) / 4); j += kSyncThreads) reinterpret_cast<uint32_t*>(&hd)[j] = reinterpret_cast<const uint32_t*>(d.hd)[j];
+    const jd::Sel sel = jd::make_sel(d.hd);
     __syncthreads();
     if (i >= d.nsub) return;
+    const Header* hd = d.hd;
     const uint32_t w0 = blockIdx.x * (uint32_t)(kSyncThreads * jd::SUB_WORDS);
     const int seg = d.sub_seg[i];
     const uint32_t seg_end = d.seg_end_bit[seg];
     uint32_t bound = (uint32_t)(i + 1) * jd::SUB_BITS;
     bound = bound < seg_end ? bound : seg_end;
-    const int seg_block0 = seg * hd.ri * hd.bpm;
-    int block_end = seg_block0 + hd.ri * hd.bpm;
-    block_end = block_end < hd.total_blocks ? block_end : hd.total_blocks;
-    int n = 0;
+    const int seg_block0 = seg * hd->ri * hd->bpm;
+    int block_end = seg_block0 + hd->ri * hd->bpm;
+    block_end = block_end < hd->total_blocks ? block_end : hd->total_blocks;
     const State s = d.start[i];
     if (s.p == jd::NO_STATE || s.p < w0 * 32u) return;                    // never for a settled chain
-    (void)jd::run<true>(s, bound, seg_end, words, w0, luts, &hd, n, d.coef, d.base[i], block_end);
-}
-
-// DC prediction: coefficient 0 of the t-th block of component c (scan order) = sum of the differences since the start of
-// its restart segment.  One workgroup per component, 8 blocks per thread and round, segmented scan across the threads.
-__global__ __launch_bounds__(1024) void jpeg_dc_kernel(Dev d) {
-    constexpr int ITEMS = 8;
-    __shared__ int vals[1024];
-    __shared__ int flgs[1024];
-    __shared__ int carry_s;
-    const Header* hd = d.hd;
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const int nb = hd->comp_nblk[c], off = hd->comp_off[c], bpm = hd->bpm, ri = hd->ri;
-    const int len = hd->mx * hd->my * nb;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < len; c0 += 1024 * ITEMS) {
-        const int t0 = c0 + tid * ITEMS;
-        int v[ITEMS];
-        int run = 0, any_reset = 0;
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int t = t0 + j;
-            int diff = 0, reset = 0;
-            if (t < len) {
-                const int mcu = t / nb, jj = t - mcu * nb;
-                reset = jj == 0 && mcu % ri == 0;
-                diff = d.coef[(size_t)(mcu * bpm + off + jj) * 64];
-            }
-            run = reset ? diff : run + diff;
-            any_reset |= reset;
-            v[j] = run;
-        }
-        vals[tid] = run;
-        flgs[tid] = any_reset;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int a = vals[tid], g = flgs[tid];
-            if (tid >= o && !g) { a += vals[tid - o]; g = flgs[tid - o]; }
-            __syncthreads();
-            vals[tid] = a;
-            flgs[tid] = g;
-            __syncthreads();
-        }
-        // carry into this thread = inclusive value of the previous thread (+ the chunk carry if no reset before it)
-        int carry = 0;
-        if (tid > 0) carry = vals[tid - 1] + (flgs[tid - 1] ? 0 : carry_s); else carry = carry_s;
-        const int last_incl = vals[1023] + (flgs[1023] ? 0 : carry_s);
-        bool seen = false;
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int t = t0 + j;
-            if (t < len) {
-                const int mcu = t / nb, jj = t - mcu * nb;
-                seen |= jj == 0 && mcu % ri == 0;
-                d.coef[(size_t)(mcu * bpm + off + jj) * 64] = (int16_t)(v[j] + (seen ? 0 : carry));
-            }
-        }
-        __syncthreads();
-        if (tid == 0) carry_s = last_incl;
-        __syncthreads();
-    }
+    const int4 b = d.base[i];
+    const int32_t pred[3] = {b.y, b.z, b.w};
+    jd::Counts c;
+    (void)jd::run<true>(s, bound, seg_end, words, w0, luts, sel, c, d.coef, b.x, block_end, pred);
 }
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -497,7 +466,7 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
     for (int c = 0; c < hd.ncomp; ++c) planes_bytes = (size_t)hd.plane_off[c] + wt::align_up((size_t)hd.plane_pitch[c] * hd.plane_rows[c]);
     size_t woff = 0;
     auto take = [&](size_t b) { const size_t o = woff; woff += wt::align_up(b); return o; };
-    const size_t o_nblk = take((size_t)L.max_sub * 4), o_base = take((size_t)L.max_sub * 4), o_flags = take(64);
+    const size_t o_cnt = take((size_t)L.max_sub * 16), o_base = take((size_t)L.max_sub * 16), o_flags = take(64);
     const size_t o_coef = take((size_t)hd.total_blocks * 128), o_planes = take(planes_bytes);
     Ctx* ctx = acquire();
     Release rel{ctx};
@@ -506,7 +475,7 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
     memcpy(ctx->host + L.header, &hd, sizeof(Header));
     memcpy(ctx->host + L.luts, p.luts, sizeof(p.luts));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t used = L.stream + (size_t)hd.nsub * 128 + 16;
+    const size_t used = L.stream + (size_t)hd.nsub * jd::SUB_BYTES + 16;
     WT_HIP(hipMemcpyAsync(ctx->dev, ctx->host, used, hipMemcpyHostToDevice, st));
     WT_HIP(hipMemsetAsync(ctx->work, 0, o_coef + (size_t)hd.total_blocks * 128, st));       // nblk, base, flags, coefficients
     Dev d;
@@ -518,19 +487,18 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
     d.start = reinterpret_cast<State*>(ctx->dev + L.start);
     d.exit = reinterpret_cast<State*>(ctx->dev + L.exit);
     d.stream = reinterpret_cast<const uint32_t*>(ctx->dev + L.stream);
-    d.nblk = reinterpret_cast<int32_t*>(ctx->work + o_nblk);
-    d.base = reinterpret_cast<int32_t*>(ctx->work + o_base);
+    d.cnt = reinterpret_cast<int4*>(ctx->work + o_cnt);
+    d.base = reinterpret_cast<int4*>(ctx->work + o_base);
     d.flags = reinterpret_cast<int32_t*>(ctx->work + o_flags);
     d.coef = reinterpret_cast<int16_t*>(ctx->work + o_coef);
     d.planes = ctx->work + o_planes;
     d.nsub = hd.nsub;
-    d.stream_words = hd.nsub * jd::SUB_WORDS + 4;
+    d.stream_words = hd.nsub * jd::SUB_WORDS + 4;      // 16 bytes of 1-bits follow the last subsequence
     const unsigned sync_grid = (unsigned)((hd.nsub + kSyncThreads - 1) / kSyncThreads);
     int rounds = 0;
     auto tail = [&]() -> int {
         hipLaunchKernelGGL(jpeg_scan_kernel, dim3(1), dim3(1024), 0, st, d);
         hipLaunchKernelGGL(jpeg_write_kernel, dim3(sync_grid), dim3(kSyncThreads), 0, st, d);
-        hipLaunchKernelGGL(jpeg_dc_kernel, dim3((unsigned)hd.ncomp), dim3(1024), 0, st, d);
         hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((hd.total_blocks + 31) / 32)), dim3(256), 0, st, d);
         const int fh = hd.ncomp == 3 ? hd.hmax / hd.comp_h[1] : 1, fv = hd.ncomp == 3 ? hd.vmax / hd.comp_v[1] : 1;
         const dim3 grid((unsigned)(((hd.width + fh - 1) / fh + 63) / 64), (unsigned)(((hd.height + fv - 1) / fv + 3) / 4));

@@ -12,6 +12,7 @@ using jd::HuffLut;
 using jd::State;
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+constexpr size_t SB = jd::SUB_BYTES;
 
 struct Parsed {
     Header hd;
@@ -23,20 +24,20 @@ struct Parsed {
 inline void derive(const uint8_t* bits, const uint8_t* vals, int nvals, HuffLut& lut) {
     memset(&lut, 0, sizeof(lut));
     memcpy(lut.vals, vals, (size_t)nvals);
-    int code = 0, k = 0;
+    uint32_t code = 0;
+    int k = 0;
     for (int l = 1; l <= 16; ++l) {
-        lut.valoff[l] = k - code;
+        if (l >= 9) lut.valoff[l - 9] = (uint16_t)((uint32_t)k - code);
         for (int i = 0; i < bits[l - 1]; ++i, ++k, ++code) {
             if (l <= 8) {
-                const int lo = code << (8 - l);
-                for (int j = 0; j < (1 << (8 - l)); ++j)
+                const uint32_t lo = code << (8 - l);
+                for (uint32_t j = 0; j < (1u << (8 - l)); ++j)
                     if (lo + j < 256) lut.fast[lo + j] = (uint16_t)((l << 8) | vals[k]);
             }
         }
-        lut.maxcode[l] = bits[l - 1] ? code - 1 : -1;
+        if (l >= 9) lut.limit[l - 9] = code << (16 - l);                 // an over-full table (corrupt DHT) only makes codes unreachable
         code <<= 1;
     }
-    lut.maxcode[17] = 0x7fffffff;
 }
 
 inline const char* parse(const uint8_t* d, size_t n, Parsed& out) {
@@ -173,7 +174,7 @@ struct Layout {
 inline Layout layout_for(size_t file_bytes, size_t scan_pos, int nseg) {
     Layout L;
     const size_t scan_max = file_bytes - scan_pos;
-    L.max_sub = (int)(scan_max / 128 + (size_t)nseg + 2);
+    L.max_sub = (int)(scan_max / SB + (size_t)nseg + 2);
     size_t off = 0;
     auto take = [&](size_t b) { const size_t o = off; off += align_up(b); return o; };
     L.header = take(sizeof(Header));
@@ -183,17 +184,17 @@ inline Layout layout_for(size_t file_bytes, size_t scan_pos, int nseg) {
     L.sub_seg = take((size_t)L.max_sub * 4);
     L.start = take((size_t)L.max_sub * sizeof(State));
     L.exit = take((size_t)L.max_sub * sizeof(State));
-    L.stream = take((size_t)L.max_sub * 128 + 16);
+    L.stream = take((size_t)L.max_sub * SB + 16);
     L.total = off;
     return L;
 }
 
-// Unstuff the entropy-coded bytes into `stream`, one 128-byte-aligned run per restart segment, padded with 1-bits.
+// Unstuff the entropy-coded bytes into `stream`, one subsequence-aligned run per restart segment, padded with 1-bits.
 inline const char* unstuff(const uint8_t* d, size_t n, size_t pos, const Layout& L, int nseg_expected, uint8_t* blob, Header& hd) {
     uint8_t* stream = blob + L.stream;
     uint32_t* seg_first = reinterpret_cast<uint32_t*>(blob + L.seg_first_sub);
     uint32_t* seg_end = reinterpret_cast<uint32_t*>(blob + L.seg_end_bit);
-    const size_t cap = (size_t)L.max_sub * 128;
+    const size_t cap = (size_t)L.max_sub * SB;
     size_t w = 0;                     // write offset in stream
     int seg = 0;
     seg_first[0] = 0;
@@ -211,26 +212,26 @@ inline const char* unstuff(const uint8_t* d, size_t n, size_t pos, const Layout&
         if (nb == 0xFF) { pos += 1; continue; }                           // fill byte
         if (nb >= 0xD0 && nb <= 0xD7) {
             seg_end[seg] = (uint32_t)(w * 8);
-            const size_t padded = (w + 127) / 128 * 128;
+            const size_t padded = (w + SB - 1) / SB * SB;
             memset(stream + w, 0xFF, padded - w);
             w = padded;
             ++seg;
             if (seg >= nseg_expected) return ("more restart markers than the restart interval allows");
-            seg_first[seg] = (uint32_t)(w / 128);
+            seg_first[seg] = (uint32_t)(w / SB);
             pos += 2;
             continue;
         }
         end = true;                                                         // EOI or any other marker ends the scan
     }
     seg_end[seg] = (uint32_t)(w * 8);
-    const size_t padded = (w + 127) / 128 * 128;
+    const size_t padded = (w + SB - 1) / SB * SB;
     memset(stream + w, 0xFF, padded - w + 16);
     w = padded;
     ++seg;
     if (seg != nseg_expected) return ("restart markers do not match the restart interval (truncated or corrupt file)");
-    seg_first[seg] = (uint32_t)(w / 128);
+    seg_first[seg] = (uint32_t)(w / SB);
     hd.nseg = seg;
-    hd.nsub = (int)(w / 128);
+    hd.nsub = (int)(w / SB);
     if (hd.nsub < 1) return ("empty scan");
     // per-subsequence tables: segment, start (unknown), exit (a guess: the next boundary, block 0, DC next)
     int32_t* sub_seg = reinterpret_cast<int32_t*>(blob + L.sub_seg);
