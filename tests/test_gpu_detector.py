@@ -273,7 +273,12 @@ def test_inference_cli_on_image_folder(tmp_path):
     for seg, ts, cam in names:
         d = root / seg / str(ts)
         d.mkdir(parents=True, exist_ok=True)
-        Image.fromarray(rng.integers(30, 200, (96, 160, 3), dtype=np.uint8)).save(d / (cam + '.png'))
+        # two camera frames as JPEG (decoded by the HIP decoder inside the loader), two as PNG (PIL, as in the reference)
+        arr = rng.integers(30, 200, (96, 160, 3), dtype=np.uint8)
+        if seg == 'segA':
+            Image.fromarray(arr).save(d / (cam + '.jpg'), quality=92)
+        else:
+            Image.fromarray(arr).save(d / (cam + '.png'))
     model = _random_model_file(tmp_path)
     out = tmp_path / 'sub.json'
     rows0 = I.main(['-m', model, '-i', str(root), '--export', str(out), '--batch-size=1', '--tta', 'x1.5,hflip', '-o', str(tmp_path / 'o')])
