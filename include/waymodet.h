@@ -213,6 +213,9 @@ int wd_jpeg_info(const uint8_t* data, int64_t n, int32_t* width, int32_t* height
                  int32_t* v_samp, int32_t* restart_interval);
 int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rgb, int64_t capacity, int32_t* width, int32_t* height,
                           int32_t* sync_rounds, void* stream);
+/* Statistics of the calling thread's last decode: out4 = {synchronisation launches, most iterations a workgroup needed inside
+ * one launch, subsequence decodes in total over all launches, subsequences} (host-only). */
+int wd_jpeg_last_stats(int32_t* out4);
 
 #ifdef __cplusplus
 }

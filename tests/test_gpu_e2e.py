@@ -247,6 +247,46 @@ def test_graph_replay_equals_eager_launches():
         torch.cuda.tunable.enable(saved[2])
 
 
+def test_pipeline_with_frames_entering_as_jpeg(oracle):
+    """SURVEY 8f rank 3 inside the timed pipeline: the frames of step s + 1 are decoded on the GPU by loader threads while the
+    detector works on step s.  Every frame slot holds exactly PIL's decode of its file when its step reads it (checked after
+    each step, i.e. the decode-ahead never overwrites a slot that is still being read), the detector saw those frames (same
+    slots as a pipeline whose resident frames ARE the decoded files), and the tracker rows equal the oracle's replay."""
+    import io
+    import torch
+    from PIL import Image
+    from waymo_2d_tracking_amd.bench_e2e import DetectTrackPipeline, check_against
+    saved = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic, torch.cuda.tunable.is_enabled())
+    try:
+        pipe = DetectTrackPipeline(n_cameras=3, frames_per_camera=2, height=256, width=384, seed=3, segment_frames=12,
+                                   distinct_times=6, deterministic=True)
+        pipe.enable_jpeg_input(quality=85, workers=3)
+        ref = DetectTrackPipeline(n_cameras=3, frames_per_camera=2, height=256, width=384, seed=3, segment_frames=12,
+                                  distinct_times=6, model=pipe.model, deterministic=True)
+        for t in range(pipe.n_times):
+            for cam in range(pipe.nc):
+                dec = np.asarray(Image.open(io.BytesIO(pipe.jpeg[t][cam])).convert('RGB'))
+                ref.frames[t, cam] = torch.from_numpy(dec.copy()).cuda()
+        pipe._await_decoded(range(pipe.n_times))                        # the decodes enable_jpeg_input() started
+        torch.cuda.synchronize()
+        pipe.frames.zero_()                                             # from here on nothing but the decoder fills the slots
+        torch.cuda.synchronize()
+        for s in range(5):                                              # 5 steps x 2 times: wraps the 6 time slots
+            times = [(pipe.time + j) % pipe.n_times for j in range(pipe.fpc)]
+            pipe.step(True)
+            ref.step(True)
+            torch.cuda.synchronize()
+            for t in times:
+                assert torch.equal(pipe.frames[t], ref.frames[t]), (s, t)
+        assert torch.equal(pipe.category[:5], ref.category[:5]) and int((pipe.category[:5] != 0).sum()) > 0
+        assert torch.equal(pipe.xywhs[:5], ref.xywhs[:5])
+        rep = check_against(pipe, oracle.track_streams)
+        assert rep['ok'] and rep['chunks'] == 5, rep
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = saved[0], saved[1]
+        torch.cuda.tunable.enable(saved[2])
+
+
 def test_per_chunk_exchange_over_rccl_single_rank(tmp_path):
     """The N > 1 step (birth-count all_gather + block gather behind every chunk's SORT) exercised over RCCL with one rank
     (a fresh process: NCCL process group + hipGraph capture + side-stream collectives), then verified: the collated rows are

@@ -97,3 +97,52 @@ def test_header_parse_needs_no_gpu():
     prog = JC.encode(JC.synth(32, 32, 2), quality=80, progressive=True)
     assert lib.wd_jpeg_info(prog, ctypes.c_int64(len(prog)), *[ctypes.byref(v) for v in o]) != 0
     assert b'progressive' in lib.wt_last_error()
+
+
+FUZZ = r'''
+import sys, ctypes, numpy as np
+sys.path.insert(0, sys.argv[2])
+import jpeg_cases as JC
+lib = ctypes.CDLL(sys.argv[1])
+cap = 1 << 16
+coef = np.zeros((cap, 64), np.int16)
+def run(data):
+    rounds, total = ctypes.c_int(0), ctypes.c_int(0); geo = (ctypes.c_int * 8)(); err = ctypes.create_string_buffer(256)
+    return lib.jpeg_emul_coefficients(data, ctypes.c_long(len(data)), 256, coef.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(cap),
+                                      ctypes.byref(rounds), ctypes.byref(total), geo, err, 256)
+rng = np.random.default_rng(0)
+seeds = [d for _, d in JC.small_cases()[:12]] + [JC.medium_cases()[0][1]]
+ok = 0
+for it in range(1500):
+    d = bytearray(seeds[it % len(seeds)])
+    mode = it % 4
+    if mode == 0:
+        for _ in range(rng.integers(1, 6)):
+            d[rng.integers(0, len(d))] = rng.integers(0, 256)
+    elif mode == 1:
+        d = d[:rng.integers(2, len(d))]
+    elif mode == 2:
+        d[rng.integers(0, min(len(d), 700))] = rng.integers(0, 256)
+    else:
+        i = rng.integers(0, len(d)); d[i:i] = bytes(rng.integers(0, 256, rng.integers(1, 8)).tolist())
+    ok += run(bytes(d)) == 0
+print('FUZZ-DONE', ok)
+'''
+
+
+def test_corrupt_files_stay_inside_their_buffers(tmp_path):
+    """host parser, unstuffing and the decode loop (the code the kernels run) under AddressSanitizer + UBSan on 1500 mutated
+    files: byte flips, truncation, header damage, insertions.  (GPU sanitizers are not available on the pool; this is the CPU
+    build of the same sources.)"""
+    asan = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.exists(asan):
+        pytest.skip('no libasan')
+    so = str(tmp_path / 'libjpeg_emul_asan.so')
+    subprocess.run(['g++', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-std=c++17', '-shared', '-fPIC', '-o', so,
+                    os.path.join(ROOT, 'tests', 'native', 'jpeg_sync_emul.cpp')], check=True)
+    script = tmp_path / 'fuzz.py'
+    script.write_text(FUZZ)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS='detect_leaks=0:abort_on_error=1', UBSAN_OPTIONS='halt_on_error=1')
+    r = subprocess.run([sys.executable, str(script), so, os.path.join(ROOT, 'tests')], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'FUZZ-DONE' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr, r.stderr[-4000:]

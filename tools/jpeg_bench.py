@@ -23,6 +23,12 @@ def main():
         data = JC.encode(JC.synth(h, w, kind, seed=3), quality=q, subsampling=sub)
         out = ops.jpeg_decode(data)
         assert np.array_equal(out.cpu().numpy(), JC.pil_rgb(data))
+        import ctypes
+        from waymo_2d_tracking_amd import _lib
+        st = (ctypes.c_int32 * 4)()
+        _lib.lib().wd_jpeg_last_stats(st)
+        print('    sync launches %d, most iterations of a workgroup inside one launch %d, subsequence decodes %d for %d subsequences'
+              % tuple(st), flush=True)
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(n):

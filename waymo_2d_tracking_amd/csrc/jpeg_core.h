@@ -33,14 +33,18 @@ constexpr int SUB_WORDS = SUB_BITS / 32;
 constexpr int MAX_BPM = 10;                        // blocks per MCU (T.81 B.2.3)
 constexpr uint32_t NO_STATE = 0xFFFFFFFFu;
 
-// decoder table of one Huffman table.  Codes of <= 8 bits: one lookup with the next 8 bits.  Longer codes: canonical
-// codes are ordered, so with limit[l] = (first code value after the codes of length l) left-justified to 16 bits - a
-// non-decreasing sequence - the length of the code at the top of a 16-bit window w is 9 + #{l in 9..16 : w >= limit[l]}:
-// eight independent compares instead of jdhuff.c's bit-by-bit maxcode loop (a chain of dependent reads on a GPU).
+// decoder table of one Huffman table.  Codes of <= FAST_BITS bits: one lookup with the next FAST_BITS bits (12 bits: 8 KB per
+// table in LDS; longer codes are ~0.3 % of the symbols, so that a 64-lane wave rarely has to walk the second path).  Longer
+// codes: canonical codes are ordered, so with limit[l] = (first code value after the codes of length l) left-justified to 16
+// bits - a non-decreasing sequence - the length of the code at the top of a 16-bit window w is
+// FAST_BITS + 1 + #{l > FAST_BITS : w >= limit[l]}: independent compares instead of jdhuff.c's bit-by-bit maxcode loop (a chain of
+// dependent reads on a GPU).
+constexpr int FAST_BITS = 12;
+constexpr int SLOW_LENS = 16 - FAST_BITS;
 struct alignas(16) HuffLut {
-    uint16_t fast[256];                            // (length << 8) | symbol for codes of <= 8 bits, 0 = longer / invalid
-    uint32_t limit[8];                             // lengths 9..16
-    uint16_t valoff[8];                            // lengths 9..16: (vals index of the first code of length l - that code) mod 2^16
+    uint16_t fast[1 << FAST_BITS];                 // (length << 8) | symbol, 0 = longer code / no code
+    uint32_t limit[SLOW_LENS];                     // lengths FAST_BITS + 1 .. 16
+    uint32_t valoff[SLOW_LENS];                    // (vals index of the first code of length l - that code) mod 2^16
     uint8_t vals[256];
 };
 
@@ -75,20 +79,20 @@ JD_HD bool same(const State& a, const State& b) { return a.p == b.p && a.bk == b
 // one Huffman symbol from the top of `win`; returns the code length (0 = no code: only in padding or out of step)
 template <class LutPtr>
 JD_HD int symbol(LutPtr lut, uint32_t win, int& sym) {
-    const uint32_t f = lut->fast[win >> 24];
+    const uint32_t f = lut->fast[win >> (32 - FAST_BITS)];
+    if (f) { sym = (int)(f & 255); return (int)(f >> 8); }
     const uint32_t w16 = win >> 16;
-    uint32_t vo[8];
-    int l = 9;
+    uint32_t vo[SLOW_LENS];
+    int l = FAST_BITS + 1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < SLOW_LENS; ++j) {
         l += w16 >= lut->limit[j] ? 1 : 0;
         vo[j] = lut->valoff[j];
     }
-    if (f) { sym = (int)(f & 255); return (int)(f >> 8); }
     if (l > 16) return 0;
     uint32_t v = vo[0];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) v = l - 9 == j ? vo[j] : v;
+    for (int j = 1; j < SLOW_LENS; ++j) v = l - (FAST_BITS + 1) == j ? vo[j] : v;
     sym = lut->vals[((win >> (32 - l)) + v) & 255];
     return l;
 }

@@ -46,7 +46,7 @@ struct Dev {                         // device pointers into the blob + work buf
     int4* base;                      // per subsequence: first block index, DC predictions at its start
     int16_t* coef;
     uint8_t* planes;
-    int32_t* flags;                  // [0] chain not settled, [1] a segment came up short
+    int32_t* flags;                  // [0] chain not settled, [1] a segment came up short, [2] / [3] statistics
     int nsub, stream_words;
 };
 
@@ -90,7 +90,9 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
     }
     exits[tid] = e_cur;
     __syncthreads();
+    int iters = 0, decodes = 0;
     for (;;) {
+        ++iters;
         State want;
         if (first) { want.p = (uint32_t)i * jd::SUB_BITS; want.bk = 0; }
         else {
@@ -102,12 +104,16 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
         int changed = 0;
         if (valid && !jd::same(want, s_cur)) {
             s_cur = want;
+            ++decodes;
             const State e = jd::run<false>(s_cur, bound, seg_end, words, w0, luts, sel, c_cur, nullptr, 0, 0, nullptr);
             if (!jd::same(e, e_cur)) { e_cur = e; exits[tid] = e; changed = 1; }
         }
         if (!__syncthreads_or(changed)) break;
     }
     if (valid) { d.start[i] = s_cur; d.exit[i] = e_cur; d.cnt[i] = make_int4(c_cur.n, c_cur.dc[0], c_cur.dc[1], c_cur.dc[2]); }
+    // statistics (wd_jpeg_last_stats): longest iteration count of a workgroup, subsequence decodes in total
+    if (tid == 0) atomicMax(&d.flags[2], iters);
+    if (decodes) atomicAdd(&d.flags[3], decodes);
 }
 
 // one workgroup: is every start state the exit state of its predecessor (or the known segment start)?  Running values of
@@ -432,7 +438,15 @@ int grow(Ctx& c, size_t blob, size_t work) {
     return WT_OK;
 }
 
+thread_local int32_t t_stats[4] = {0, 0, 0, 0};
+
 }  // namespace
+
+extern "C" int wd_jpeg_last_stats(int32_t* out4) {
+    if (!out4) return fail("no output");
+    for (int k = 0; k < 4; ++k) out4[k] = t_stats[k];
+    return WT_OK;
+}
 
 extern "C" int wd_jpeg_info(const uint8_t* data, int64_t n, int32_t* width, int32_t* height, int32_t* components,
                             int32_t* h_samp, int32_t* v_samp, int32_t* restart_interval) {
@@ -507,7 +521,7 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
         else if (fv == 1) hipLaunchKernelGGL(jpeg_color_kernel<1>, grid, dim3(256), 0, st, d, rgb);
         else hipLaunchKernelGGL(jpeg_color_kernel<2>, grid, dim3(256), 0, st, d, rgb);
         WT_HIP(hipGetLastError());
-        WT_HIP(hipMemcpyAsync(ctx->host_flags, d.flags, 8, hipMemcpyDeviceToHost, st));
+        WT_HIP(hipMemcpyAsync(ctx->host_flags, d.flags, 16, hipMemcpyDeviceToHost, st));
         WT_HIP(hipStreamSynchronize(st));
         return WT_OK;
     };
@@ -521,6 +535,7 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
         WT_TRY(tail());
     }
     if (sync_rounds) *sync_rounds = rounds;
+    t_stats[0] = rounds; t_stats[1] = ctx->host_flags[2]; t_stats[2] = ctx->host_flags[3]; t_stats[3] = hd.nsub;
     if (ctx->host_flags[1]) return fail("entropy-coded data ends before the last block (truncated or corrupt file)");
     return WT_OK;
 }

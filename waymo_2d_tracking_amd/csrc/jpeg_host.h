@@ -22,20 +22,21 @@ struct Parsed {
 };
 
 inline void derive(const uint8_t* bits, const uint8_t* vals, int nvals, HuffLut& lut) {
+    constexpr int FB = jd::FAST_BITS;
     memset(&lut, 0, sizeof(lut));
     memcpy(lut.vals, vals, (size_t)nvals);
     uint32_t code = 0;
     int k = 0;
     for (int l = 1; l <= 16; ++l) {
-        if (l >= 9) lut.valoff[l - 9] = (uint16_t)((uint32_t)k - code);
+        if (l > FB) lut.valoff[l - FB - 1] = ((uint32_t)k - code) & 0xffffu;
         for (int i = 0; i < bits[l - 1]; ++i, ++k, ++code) {
-            if (l <= 8) {
-                const uint32_t lo = code << (8 - l);
-                for (uint32_t j = 0; j < (1u << (8 - l)); ++j)
-                    if (lo + j < 256) lut.fast[lo + j] = (uint16_t)((l << 8) | vals[k]);
+            if (l <= FB) {
+                const uint32_t lo = code << (FB - l);
+                for (uint32_t j = 0; j < (1u << (FB - l)); ++j)
+                    if (lo + j < (1u << FB)) lut.fast[lo + j] = (uint16_t)((l << 8) | vals[k]);
             }
         }
-        if (l >= 9) lut.limit[l - 9] = code << (16 - l);                 // an over-full table (corrupt DHT) only makes codes unreachable
+        if (l > FB) lut.limit[l - FB - 1] = code << (16 - l);            // an over-full table (corrupt DHT) only makes codes unreachable
         code <<= 1;
     }
 }
@@ -158,7 +159,7 @@ inline const char* parse(const uint8_t* d, size_t n, Parsed& out) {
         hd.dh[c] = (hd.height * hd.comp_v[c] + hd.vmax - 1) / hd.vmax;
     }
     const long mcus = (long)hd.mx * hd.my;
-    if (mcus * hd.bpm > (1L << 26)) return ("image too large");
+    if (mcus * hd.bpm > (1L << 23)) return ("image too large (more than 2^23 blocks)");
     hd.ri = dri > 0 && dri < mcus ? dri : (int)mcus;
     hd.total_blocks = (int)(mcus * hd.bpm);
     out.expected_segments = (int)((mcus + hd.ri - 1) / hd.ri);

@@ -437,7 +437,7 @@ def jpeg_info(data):
     return tuple(v.value for v in o)
 
 
-def jpeg_decode(data, device=None, return_rounds=False):
+def jpeg_decode(data, device=None, return_rounds=False, out=None):
     """bytes of a JPEG file -> (H, W, 3) uint8 RGB tensor on the GPU, bit-exact with
     `PIL.Image.open(...).convert('RGB')` (the reference's decode, detnet/inference.py:170).  Huffman decoding, inverse DCT,
     chroma upsampling and colour conversion all run in HIP kernels (csrc/jpeg_decode.hip); no host decoder is involved.
@@ -445,7 +445,10 @@ def jpeg_decode(data, device=None, return_rounds=False):
     buf = bytes(data)
     w, h = C.c_int32(0), C.c_int32(0)
     _lib.check(_lib.lib().wd_jpeg_info(buf, C.c_int64(len(buf)), C.byref(w), C.byref(h), None, None, None, None), 'wd_jpeg_info')
-    out = torch.empty((h.value, w.value, 3), dtype=torch.uint8, device=device or 'cuda')
+    if out is None:
+        out = torch.empty((h.value, w.value, 3), dtype=torch.uint8, device=device or 'cuda')
+    else:                                                                         # decode into a caller-owned frame slot
+        assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and tuple(out.shape) == (h.value, w.value, 3)
     rounds = C.c_int32(0)
     _lib.check(_lib.lib().wd_jpeg_decode_rgb_u8(buf, C.c_int64(len(buf)), _p(out), C.c_int64(out.numel()), C.byref(w), C.byref(h),
                                                 C.byref(rounds), _stream()), 'wd_jpeg_decode_rgb_u8')
