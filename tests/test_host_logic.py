@@ -310,3 +310,28 @@ def test_round_score_halfway_deviation_is_explicit():
     diff = np.abs(rows['score'] - numpy_way)
     assert (diff > 0).any() and diff.max() < 1.0000001e-5                               # differs, by exactly one unit
     assert rows['bbox'].tolist() == [[10, 20, 30, 40]] * len(scores)                    # astype(int): truncation
+
+
+def test_autocontrast_lut_equals_pil_for_every_range():
+    """ImageOps.autocontrast builds lut[v] = int(v * (255.0 / (hi - lo)) + (-lo * scale)) in Python floats; the tensor version must
+    round the same way for EVERY (lo, hi) - a reciprocal-multiply instead of the division moves 131 -> 150 instead of 149 at
+    (lo, hi) = (1, 222) (found through a JPEG-decoded test image).  All 32 640 ranges, on CPU tensors (the same torch code runs
+    on the GPU in the loader)."""
+    import torch
+    from waymo_2d_tracking_amd.detnet.inference import autocontrast_
+    v = np.arange(256)
+    bad = []
+    for lo in range(0, 255):
+        his = np.arange(lo + 1, 256)
+        # one 3-channel image per 3 values of hi: channel c holds the values {lo, hi_c} plus the full ramp clipped to that range
+        for k in range(0, len(his), 3):
+            hs = [int(his[min(k + c, len(his) - 1)]) for c in range(3)]
+            img = np.stack([np.clip(v, lo, h) for h in hs], -1).astype(np.uint8).reshape(1, 256, 3)
+            got = autocontrast_(torch.from_numpy(img)).numpy()[0]
+            for c, h in enumerate(hs):
+                scale = 255.0 / (h - lo)
+                offset = -lo * scale
+                exp = np.array([min(255, max(0, int(x * scale + offset))) for x in np.clip(v, lo, h)])
+                if not np.array_equal(got[:, c], exp):
+                    bad.append((lo, h))
+    assert not bad, bad[:10]

@@ -135,7 +135,7 @@ def autocontrast_(img_u8):
     hi = flat.amax(0).double()
     v = torch.arange(256, dtype=torch.float64, device=img_u8.device).unsqueeze(1)
     span = torch.where(hi > lo, hi - lo, torch.ones_like(hi))
-    scale = 255.0 / span
+    scale = torch.full_like(span, 255.0) / span          # true division: `255.0 / tensor` is reciprocal * 255 in torch (one ulp off PIL's scale)
     lut = torch.trunc(v * scale + (-lo * scale)).clamp_(0, 255)
     lut = torch.where((hi > lo).unsqueeze(0), lut, v.expand(-1, lut.shape[1])).to(torch.uint8)      # (256, C)
     out = torch.gather(lut, 0, flat.long())
