@@ -136,17 +136,24 @@ __device__ __forceinline__ uint4 pp_make_entry(bool pixel_in_image, int yy, int 
 // Per-layer pre-pass, fused with the offset conv's tap gather (det_misc.hip tap_shift_add_kernel, same arithmetic and order):
 // thread = (tile, pixel, tap).  Writes the two offsets of the tap (NHWC, 18 per pixel) and the table entry.
 // table[tile][pixel * 9 + tap], tile = (n * tiles_y + ty) * tiles_x + tx; slots of pixels outside the image hold the zero-pixel entry.
-__global__ __launch_bounds__(256) void deform_offsets_table_kernel(const float* __restrict__ partial, int ld,
+// One workgroup = one tile, one thread = one of its 576 entries.  Behind the table: one word per tile, 1 if any of the tile's samples
+// takes the far path (plain stores, no state between launches) - see the far-free loop copy of the 16-channel kernel.
+__device__ __forceinline__ void pp_tile_flag(bool far, int tile, int ntiles, uint4* __restrict__ table) {
+    const int any = __syncthreads_or(far ? 1 : 0);
+    if (threadIdx.x == 0) reinterpret_cast<unsigned*>(table + (size_t)ntiles * pp::NE)[tile] = any ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(576) void deform_offsets_table_kernel(const float* __restrict__ partial, int ld,
                                                                   const float* __restrict__ bias, int batch, int H, int W,
                                                                   float* __restrict__ offsets, uint4* __restrict__ table) {
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
-    const long total = (long)batch * tiles_y * tiles_x * pp::NE;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int e = (int)(i % pp::NE);
-        long tile = i / pp::NE;
-        const int tx = (int)(tile % tiles_x);
+    const int ntiles = batch * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int e = threadIdx.x;
+        int tile = t;
+        const int tx = tile % tiles_x;
         tile /= tiles_x;
-        const int ty = (int)(tile % tiles_y), tn = (int)(tile / tiles_y);
+        const int ty = tile % tiles_y, tn = tile / tiles_y;
         const int pxl = e / 9, k = e - 9 * pxl;
         const int yy = pxl >> 3, xx = pxl & 7, kh = k / 3, kw = k - 3 * kh;
         const int oy = ty * 8 + yy, ox = tx * 8 + xx;
@@ -170,29 +177,33 @@ __global__ __launch_bounds__(256) void deform_offsets_table_kernel(const float* 
             ov = make_float2(a0, a1);
             *reinterpret_cast<float2*>(offsets + (((size_t)tn * H + oy) * W + ox) * 18 + 2 * k) = ov;
         }
-        table[i] = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, H, W, 1);
+        const uint4 ent = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, H, W, 1);
+        table[(size_t)t * pp::NE + e] = ent;
+        pp_tile_flag(ent.y == pp::FAR_Y, t, ntiles, table);
     }
 }
 
 // The same table from an offsets tensor (N, H, W, 18) that already exists (callers without the fused pre-pass).
 // H, W: the OUTPUT grid (tiles, offsets); Hin, Win: the sampled image (== H, W at stride 1).
-__global__ __launch_bounds__(256) void deform_table_kernel(const float* __restrict__ offsets, int batch, int Hin, int Win, int H, int W,
+__global__ __launch_bounds__(576) void deform_table_kernel(const float* __restrict__ offsets, int batch, int Hin, int Win, int H, int W,
                                                           int stride, uint4* __restrict__ table) {
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
-    const long total = (long)batch * tiles_y * tiles_x * pp::NE;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int e = (int)(i % pp::NE);
-        long tile = i / pp::NE;
-        const int tx = (int)(tile % tiles_x);
+    const int ntiles = batch * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int e = threadIdx.x;
+        int tile = t;
+        const int tx = tile % tiles_x;
         tile /= tiles_x;
-        const int ty = (int)(tile % tiles_y), tn = (int)(tile / tiles_y);
+        const int ty = tile % tiles_y, tn = tile / tiles_y;
         const int pxl = e / 9, k = e - 9 * pxl;
         const int yy = pxl >> 3, xx = pxl & 7, kh = k / 3, kw = k - 3 * kh;
         const int oy = ty * 8 + yy, ox = tx * 8 + xx;
         const bool in = oy < H && ox < W;
         float2 ov = make_float2(0.f, 0.f);
         if (in) ov = *reinterpret_cast<const float2*>(offsets + (((size_t)tn * H + oy) * W + ox) * 18 + 2 * k);
-        table[i] = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, Hin, Win, stride);
+        const uint4 ent = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, Hin, Win, stride);
+        table[(size_t)t * pp::NE + e] = ent;
+        pp_tile_flag(ent.y == pp::FAR_Y, t, ntiles, table);
     }
 }
 
@@ -247,9 +258,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     }
 
     struct TileXY { int tn, ty, tx; };
-    auto tile_xy = [&](int it) {
-        int t = t0 + team + 2 * it;
-        t = t < t1 ? t : t1 - 1;
+    auto tile_of = [&](int t) {                 // work-order tile number -> (image, tile row, tile column)
         TileXY r;
         r.tn = t / (tiles_y * tiles_x);
         const int trem = t - r.tn * tiles_y * tiles_x;
@@ -260,6 +269,11 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         if (2 * band + 1 < tiles_y) { r.tx = rb >> 1; r.ty = 2 * band + (rb & 1); }
         else { r.tx = rb; r.ty = 2 * band; }
         return r;
+    };
+    auto tile_xy = [&](int it) {
+        int t = t0 + team + 2 * it;
+        t = t < t1 ? t : t1 - 1;
+        return tile_of(t);
     };
     auto tile_valid = [&](int it) { return t0 + team + 2 * it < t1; };
 
@@ -439,9 +453,10 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     };
     // requests of the prepared tap: its corners -> cv (LDS; lanes whose sample left the patch: global memory, same registers, a
     // corner outside the image gets weight 0) and the weights of tap k -> bb
-    auto issue_reads = [&](int k, f32x4 (&bb)[NQ], bool want_w, int tn) {
+    auto issue_reads = [&](auto FARC, int k, f32x4 (&bb)[NQ], bool want_w, int tn) {
+        constexpr bool FAR = decltype(FARC)::value;
 #ifndef PP_NO_FAR
-        if (__builtin_expect(__ballot(far_nxt) != 0, 0)) {
+        if (FAR && __builtin_expect(__ballot(far_nxt) != 0, 0)) {
             if (far_nxt) {
                 const int ih = (int)(ent.x & 0xFFFFu) - 32768, iw = (int)(ent.x >> 16) - 32768;
                 const bool y0 = ih >= 0 && ih < H, y1 = ih + 1 >= 0 && ih + 1 < H, x0 = iw >= 0 && iw < W, x1 = iw + 1 >= 0 && iw + 1 < W;
@@ -526,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     unsigned tab_cur = tab_b0, tab_nxt = tab_b0 + pp::TAB_B;               // ... of the two table buffers
     bool have_next = false;
     int it = 0;
-    auto tap = [&](auto K) {
+    auto tap = [&](auto K, auto FARC) {
         constexpr int k = decltype(K)::value;
         constexpr int kn = (k + 1) % 9;
         // ---- G(k) ----
@@ -537,8 +552,8 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         }
         blend();
         prep(k == 8 ? base_nxt : base_cur);                       // the next tap lives in the next tile's patch when k == 8
-        if constexpr (kn < RW) issue_reads(kn, b[0], false, k == 8 ? nxt.tn : cur.tn);
-        else issue_reads(kn, b[(k + 1) & 1], true, k == 8 ? nxt.tn : cur.tn);
+        if constexpr (kn < RW) issue_reads(FARC, kn, b[0], false, k == 8 ? nxt.tn : cur.tn);
+        else issue_reads(FARC, kn, b[(k + 1) & 1], true, k == 8 ? nxt.tn : cur.tn);
         // side jobs: the compiler waits for ALL vector-memory operations right before the next tap's corner requests (the corner
         // registers may be the target of global loads), so stores and DMA requests are issued right behind this tap's and have a
         // whole tap to complete
@@ -579,18 +594,42 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     // first tap of the first tile: entry, addresses, corner + weight reads in flight before the loop
     read_entry(tab_cur, 0);
     prep(base_cur);
-    if constexpr (RW > 0) issue_reads(0, b[0], false, cur.tn);
-    else issue_reads(0, b[0], true, cur.tn);
+    // 16 channels per group: does any tile of this workgroup hold a far sample?  (one word per tile behind the table, written by the
+    // pre-pass; every wave reads them itself: no barrier)
+    bool wg_far = true;
+    if constexpr (CG == 16) {
+        const unsigned* tflag = reinterpret_cast<const unsigned*>(table + (size_t)ntiles * pp::NE);
+        wg_far = false;
+        for (int t = t0 + lane; t < t1; t += 64) {
+            const TileXY T = tile_of(t);
+            wg_far |= tflag[(T.tn * tiles_y + T.ty) * tiles_x + T.tx] != 0u;
+        }
+        wg_far = __ballot(wg_far) != 0;
+    }
+    if constexpr (RW > 0) issue_reads(std::true_type{}, 0, b[0], false, cur.tn);
+    else issue_reads(std::true_type{}, 0, b[0], true, cur.tn);
     read_entry(tab_cur, 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (it = 0; it < n_items; ++it) {
-        tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
-        tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-        tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
-        prev = cur; prev_valid = tile_valid(it); cur = nxt;
-        unsigned tb = base_cur; base_cur = base_nxt; base_nxt = tb;
-        tb = tab_cur; tab_cur = tab_nxt; tab_nxt = tb;
+    auto items = [&](auto FARC) {
+        for (it = 0; it < n_items; ++it) {
+            tap(std::integral_constant<int, 0>{}, FARC); tap(std::integral_constant<int, 1>{}, FARC); tap(std::integral_constant<int, 2>{}, FARC);
+            tap(std::integral_constant<int, 3>{}, FARC); tap(std::integral_constant<int, 4>{}, FARC); tap(std::integral_constant<int, 5>{}, FARC);
+            tap(std::integral_constant<int, 6>{}, FARC); tap(std::integral_constant<int, 7>{}, FARC); tap(std::integral_constant<int, 8>{}, FARC);
+            prev = cur; prev_valid = tile_valid(it); cur = nxt;
+            unsigned tb = base_cur; base_cur = base_nxt; base_nxt = tb;
+            tb = tab_cur; tab_cur = tab_nxt; tab_nxt = tb;
+        }
+    };
+    // The far path's global loads into the corner registers make hipcc wait for ALL outstanding vector-memory operations (DMA,
+    // epilogue stores) before every corner read, even when no lane takes it.  16 channels per group: a second copy of the loop without
+    // the far path runs when none of the workgroup's tiles needs it (+8 % at offsets below 1 px).  32 channels per group: the shared
+    // register allocation of two copies spills inside the far-capable one (2 px: +9 % time) - one loop there.
+    if constexpr (CG == 16) {
+        if (wg_far) items(std::true_type{});
+        else items(std::false_type{});
+    } else {
+        items(std::true_type{});
     }
     done[0] = acc[0] + acc[2]; done[1] = acc[1] + acc[3];
     epilogue();
@@ -643,11 +682,8 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
     if (!table || stride != 1) {
         void* scratch = nullptr;
         WT_TRY(scratch_table(wd_deform_table_bytes(batch, ho, wo), stream, &scratch));
-        const long total = (long)ntiles * pp::NE;
-        long blocks = (total + 255) / 256;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(deform_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, offset, batch, h, w, ho, wo, stride,
-                           (uint4*)scratch);
+        hipLaunchKernelGGL(deform_table_kernel, dim3((unsigned)(ntiles < 65535 ? ntiles : 65535)), dim3(pp::NE), 0, stream, offset, batch, h, w,
+                           ho, wo, stride, (uint4*)scratch);
         WT_HIP(hipGetLastError());
         table = scratch;
     }
@@ -686,7 +722,8 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
 }
 
 extern "C" size_t wd_deform_table_bytes(int batch, int h, int w) {
-    return (size_t)batch * ((h + 7) / 8) * ((w + 7) / 8) * pp::TAB_B;
+    const size_t ntiles = (size_t)batch * ((h + 7) / 8) * ((w + 7) / 8);
+    return ntiles * pp::TAB_B + (ntiles * 4 + 15) / 16 * 16;          // entries + one far flag (u32) per tile
 }
 
 /* Offset conv epilogue + sampling table of the persistent deformable kernel in one launch: `partial` = the (pixels, ld >= 162) GEMM
@@ -700,11 +737,9 @@ extern "C" int wd_deform_offsets_table_f32(const float* partial, int ld, const f
         wt::set_error("wd_deform_offsets_table_f32: invalid arguments (ld=%d)", ld);
         return WT_ERR_INVALID;
     }
-    const long total = (long)batch * ((h + 7) / 8) * ((w + 7) / 8) * pp::NE;
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(deform_offsets_table_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, ld, bias, batch,
-                       h, w, offsets, (uint4*)table);
+    const long ntiles = (long)batch * ((h + 7) / 8) * ((w + 7) / 8);
+    hipLaunchKernelGGL(deform_offsets_table_kernel, dim3((unsigned)(ntiles < 65535 ? ntiles : 65535)), dim3(pp::NE), 0, (hipStream_t)stream,
+                       partial, ld, bias, batch, h, w, offsets, (uint4*)table);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
