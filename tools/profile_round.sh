@@ -15,4 +15,7 @@ python3 bench.py --stage train --steps 5 --warmup 3 --no-cpu-baseline > $OUT/tra
 python3 bench.py --stage track > $OUT/track_bench_line.json 2>/dev/null
 python3 bench.py --stage ensemble > $OUT/ensemble_bench_line.json 2>/dev/null
 python3 bench.py --stage detect --no-cpu-baseline > $OUT/detect_bench_line.json 2>/dev/null
+python3 bench.py --stage decode > $OUT/jpeg_decode_bench_line.json 2>/dev/null
+python3 bench.py --from-jpeg --steps 6 --warmup 2 --no-cpu-baseline > $OUT/e2e_from_jpeg_line.json 2>/dev/null
+bash tools/jpeg_profile.sh 20 > /dev/null 2>&1; cp gpurun_out/jpeg/per_image.txt $OUT/jpeg_per_kernel.txt; cp gpurun_out/jpeg/bench.txt $OUT/jpeg_single_call_vs_pil.txt
 for f in $OUT/*_bench_line.json; do echo $f; tail -1 $f | cut -c1-170; done

@@ -40,6 +40,9 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
+#ifndef PP_SPLIT32
+#define PP_SPLIT32 0
+#endif
 namespace pp {
 constexpr int PS = 14;                 // patch side: 8 + 2 (3x3 footprint) + 2 * 2 (halo for the learned offsets)
 constexpr int NPIX = PS * PS;          // 196 (+ pixel 196 = zeros)
@@ -463,14 +466,16 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
                 w00 = (y0 && x0) ? w00 : 0.f; w01 = (y0 && x1) ? w01 : 0.f; w10 = (y1 && x0) ? w10 : 0.f; w11 = (y1 && x1) ? w11 : 0.f;
                 const int ya = min(max(ih, 0), H - 1), yb = min(max(ih + 1, 0), H - 1);
                 const int xa = min(max(iw, 0), W - 1), xc = min(max(iw + 1, 0), W - 1);
-                const float* gb = x + (long)tn * HW * C + c0 + my_ch;
-                constexpr int Q2 = CG == 32 ? 4 : 16;                 // floats from the first to the second quad
-                const float* p00 = gb + ((long)ya * W + xa) * C; const float* p01 = gb + ((long)ya * W + xc) * C;
-                const float* p10 = gb + ((long)yb * W + xa) * C; const float* p11 = gb + ((long)yb * W + xc) * C;
-                cv[0] = *reinterpret_cast<const f32x4*>(p00); cv[1] = *reinterpret_cast<const f32x4*>(p00 + Q2);
-                cv[2] = *reinterpret_cast<const f32x4*>(p01); cv[3] = *reinterpret_cast<const f32x4*>(p01 + Q2);
-                cv[4] = *reinterpret_cast<const f32x4*>(p10); cv[5] = *reinterpret_cast<const f32x4*>(p10 + Q2);
-                cv[6] = *reinterpret_cast<const f32x4*>(p11); cv[7] = *reinterpret_cast<const f32x4*>(p11 + Q2);
+                // uniform base (scalar registers) + 32-bit byte offsets per lane: feature maps are far below 4 GB
+                const char* gb = reinterpret_cast<const char*>(x + (long)tn * HW * C + c0);
+                constexpr unsigned Q2 = CG == 32 ? 16u : 64u;         // bytes from the first to the second quad
+                const unsigned ch_b = (unsigned)my_ch * 4u, rowa = (unsigned)(ya * W), rowb = (unsigned)(yb * W), cb = (unsigned)C * 4u;
+                const unsigned o00 = (rowa + (unsigned)xa) * cb + ch_b, o01 = (rowa + (unsigned)xc) * cb + ch_b;
+                const unsigned o10 = (rowb + (unsigned)xa) * cb + ch_b, o11 = (rowb + (unsigned)xc) * cb + ch_b;
+                cv[0] = *reinterpret_cast<const f32x4*>(gb + o00); cv[1] = *reinterpret_cast<const f32x4*>(gb + (o00 + Q2));
+                cv[2] = *reinterpret_cast<const f32x4*>(gb + o01); cv[3] = *reinterpret_cast<const f32x4*>(gb + (o01 + Q2));
+                cv[4] = *reinterpret_cast<const f32x4*>(gb + o10); cv[5] = *reinterpret_cast<const f32x4*>(gb + (o10 + Q2));
+                cv[6] = *reinterpret_cast<const f32x4*>(gb + o11); cv[7] = *reinterpret_cast<const f32x4*>(gb + (o11 + Q2));
             } else {
                 lds_corners();
             }
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     // 16 channels per group: does any tile of this workgroup hold a far sample?  (one word per tile behind the table, written by the
     // pre-pass; every wave reads them itself: no barrier)
     bool wg_far = true;
-    if constexpr (CG == 16) {
+    if constexpr (CG == 16 || PP_SPLIT32) {
         const unsigned* tflag = reinterpret_cast<const unsigned*>(table + (size_t)ntiles * pp::NE);
         wg_far = false;
         for (int t = t0 + lane; t < t1; t += 64) {
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     // epilogue stores) before every corner read, even when no lane takes it.  16 channels per group: a second copy of the loop without
     // the far path runs when none of the workgroup's tiles needs it (+8 % at offsets below 1 px).  32 channels per group: the shared
     // register allocation of two copies spills inside the far-capable one (2 px: +9 % time) - one loop there.
-    if constexpr (CG == 16) {
+    if constexpr (CG == 16 || PP_SPLIT32) {
         if (wg_far) items(std::true_type{});
         else items(std::false_type{});
     } else {
