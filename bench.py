@@ -51,6 +51,8 @@ def parse_args():
                     help='e2e/detect: frames in flight (hipGraph lanes on separate streams); EXPERIMENT: 2 deadlocks at 1920x1280 (spin-waiting library kernels)')
     ap.add_argument('--from-jpeg', action='store_true', help='e2e/detect: the frames enter as JPEG bytes and are decoded on the GPU inside the step '
                     '(loader threads, one step ahead); the default keeps decoded frames resident in HBM as the bench contract asks')
+    ap.add_argument('--no-defer-track', action='store_true', help='e2e: start the SORT call of a chunk right behind its last frame instead of '
+                    'behind the bottom-up pathway of the next frame (A/B of the overlap placement)')
     ap.add_argument('--no-graph', action='store_true', help='e2e/detect: launch every frame eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--no-verify', action='store_true', help='skip the oracle replay of the timed output (after the timed region)')
     return ap.parse_args()

@@ -287,6 +287,39 @@ def test_pipeline_with_frames_entering_as_jpeg(oracle):
         torch.cuda.tunable.enable(saved[2])
 
 
+def test_deferred_tracking_fills_the_same_rows(oracle):
+    """defer_tracking (the bench's placement of the SORT call: behind the bottom-up pathway of the NEXT frame, frame = two graphs)
+    produces exactly the slots and tracker rows of the plain placement, across a segment wrap, and the oracle replay agrees."""
+    import torch
+    from waymo_2d_tracking_amd.bench_e2e import DetectTrackPipeline, check_against
+    saved = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic, torch.cuda.tunable.is_enabled())
+    try:
+        a = DetectTrackPipeline(n_cameras=2, frames_per_camera=2, height=256, width=384, seed=5, segment_frames=6,
+                                distinct_times=4, deterministic=True, defer_tracking=True)
+        b = DetectTrackPipeline(n_cameras=2, frames_per_camera=2, height=256, width=384, seed=5, segment_frames=6,
+                                distinct_times=4, model=a.model, deterministic=True)
+        for s in range(5):                                              # 3 chunks per segment: wraps once
+            a.step(True)
+            b.step(True)
+            if s == 2:
+                ra, rb = check_against(a, oracle.track_streams), check_against(b, oracle.track_streams)
+                assert ra['ok'] and rb['ok'] and ra['chunks'] == rb['chunks'] == 3 and ra['rows'] == rb['rows'] > 0
+        assert a._pending_track is not None and 'graph_b' in a._lanes[0]
+        a.flush()
+        torch.cuda.synchronize()
+        assert a._pending_track is None
+        assert torch.equal(a.category[:2], b.category[:2]) and torch.equal(a.xywhs[:2], b.xywhs[:2])
+        for c in range(2):
+            k = int(a.chunk_counts[c, 0])
+            assert k == int(b.chunk_counts[c, 0]) and k > 0
+            assert torch.equal(a.out_id[c][:k], b.out_id[c][:k]) and torch.equal(a.out_bbox[c][:k], b.out_bbox[c][:k])
+        ra = check_against(a, oracle.track_streams)
+        assert ra['ok'] and ra['chunks'] == 2 and a.segments_done == 1, ra
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = saved[0], saved[1]
+        torch.cuda.tunable.enable(saved[2])
+
+
 def test_per_chunk_exchange_over_rccl_single_rank(tmp_path):
     """The N > 1 step (birth-count all_gather + block gather behind every chunk's SORT) exercised over RCCL with one rank
     (a fresh process: NCCL process group + hipGraph capture + side-stream collectives), then verified: the collated rows are

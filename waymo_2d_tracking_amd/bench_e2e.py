@@ -41,7 +41,7 @@ def moving_frames(n_cameras, n_times, height, width, seed, device):
 class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
                  iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta='',
-                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True, n_inflight=1, deterministic=False):
+                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True, n_inflight=1, deterministic=False, defer_tracking=False):
         self.dev = torch.device(device)
         # --tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image, folded into the pre-processing kernel
         self.tta_scale, self.tta_hflip = 1.0, False
@@ -104,6 +104,8 @@ class DetectTrackPipeline(object):
         self.chunk = 0                 # chunks of the current segment processed so far
         self.time = 0                  # frame time index into self.frames
         self.jpeg = None               # enable_jpeg_input(): frames enter as JPEG bytes
+        self.defer_tracking = bool(defer_tracking)
+        self._pending_track = None
         self.segments_done = 0
 
     @property
@@ -117,6 +119,12 @@ class DetectTrackPipeline(object):
         boxes, scores, classes, cnt = self.model.predict_padded(img, self.tta_scale, self.tta_hflip)
         ho, wo = self.model.last_input_size
         # HFlipTTA.post_process + Detectron2Det.predict + load_prediction in one launch; unused slots: category 0 = ignored
+        xywhs, cat = ops.detections_to_wire(boxes, scores, classes, cnt, wo, ho, self.w, self.h, self.tta_hflip)
+        return xywhs, cat, cnt
+
+    def _detect_heads(self, feats):
+        boxes, scores, classes, cnt = self.model.predict_padded_heads(feats)
+        ho, wo = self.model.last_input_size
         xywhs, cat = ops.detections_to_wire(boxes, scores, classes, cnt, wo, ho, self.w, self.h, self.tta_hflip)
         return xywhs, cat, cnt
 
@@ -138,9 +146,20 @@ class DetectTrackPipeline(object):
                     lane['gin'].copy_(self.frames[t % self.n_times, 0].unsqueeze(0))
                     self._detect_core(lane['gin'])
             lane['stream'].synchronize()
-            lane['graph'] = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream'], capture_error_mode='thread_local'):
-                lane['gout'] = self._detect_core(lane['gin'])
+            if self.defer_tracking:
+                # two graphs per frame - bottom-up pathway | FPN + RPN + heads + tail - so that an event between them can release the
+                # SORT kernel of the previous chunk (see step()); the second graph reads the first one's output tensors in place
+                lane['graph'] = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream'], capture_error_mode='thread_local'):
+                    lane['feats'] = self.model.predict_padded_bottom_up(lane['gin'], self.tta_scale, self.tta_hflip)
+                lane['graph_b'] = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(lane['graph_b'], stream=lane['stream'], pool=lane['graph'].pool(),
+                                                       capture_error_mode='thread_local'):
+                    lane['gout'] = self._detect_heads(lane['feats'])
+            else:
+                lane['graph'] = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream'], capture_error_mode='thread_local'):
+                    lane['gout'] = self._detect_core(lane['gin'])
             self._lanes.append(lane)
         torch.cuda.synchronize()
         self._graph = self._lanes[0]['graph']
@@ -195,6 +214,12 @@ class DetectTrackPipeline(object):
             for f in self._dec_pending.pop(t % self.n_times, []):
                 f.result()
 
+    def flush(self):
+        """defer_tracking: enqueue the SORT call that is still waiting for the next frame's bottom-up pass (end of a run)."""
+        if self._pending_track is not None:
+            fn, self._pending_track = self._pending_track, None
+            fn(None)
+
     def detect_frame(self, c, cam, j, eager=False):
         """Frame j of camera cam of chunk c -> wire-format detections in that frame's 100 slots."""
         # decoded uint8 HWC RGB frame -> fused pre-processing kernel (ToTensor(scaling=False) + BGR + normalise + pad)
@@ -213,9 +238,21 @@ class DetectTrackPipeline(object):
         with torch.cuda.stream(lane['stream']):
             if eager:
                 xywhs, cat, cnt = self._detect_core(img)
+                if self._pending_track is not None:              # (an instrumented frame is never the first of a step)
+                    self.flush()
             else:
                 lane['gin'].copy_(img)
                 lane['graph'].replay()
+                if self.defer_tracking:
+                    if self._pending_track is not None:
+                        # the previous chunk's SORT starts HERE: behind this frame's bottom-up pathway, i.e. under FPN / RPN / head
+                        # kernels with thousands of workgroups - not under the persistent deformable-conv kernels, whose 256 workgroups
+                        # (150 KB of LDS each) need every CU: one CU held by a tracker workgroup doubles such a launch
+                        ev = torch.cuda.Event()
+                        ev.record(lane['stream'])
+                        fn, self._pending_track = self._pending_track, None
+                        fn(ev)
+                    lane['graph_b'].replay()
                 xywhs, cat, cnt = lane['gout']
             self.xywhs[c, :, a:a + SLOTS] = xywhs
             self.category[c, a:a + SLOTS] = cat
@@ -234,6 +271,7 @@ class DetectTrackPipeline(object):
         main = torch.cuda.current_stream()
         if self.chunk == self.max_chunks:                        # segment complete: fresh trackers, slots reused
             if with_tracking:
+                self.flush()                                     # the last chunk's SORT goes first
                 with torch.cuda.stream(self.track_stream):
                     self.tracker.reset()
             self.chunk = 0
@@ -269,15 +307,24 @@ class DetectTrackPipeline(object):
         if with_tracking:
             filled = torch.cuda.Event()
             filled.record(main)
-            with torch.cuda.stream(self.track_stream):
-                self.track_stream.wait_event(filled)             # slots of this chunk are complete (eager path)
-                for ev in done:
-                    self.track_stream.wait_event(ev)             # ... on every lane
-                self.track(c)                                    # SORT of chunk c runs under the detector pass of chunk c + 1
-                if self.collate:
-                    self.rows.exchange(c)                        # (rows, births) all_gather + block gather, stream-ordered
-                self._slot_done[c] = torch.cuda.Event()
-                self._slot_done[c].record(self.track_stream)
+
+            def run_track(release, c=c, filled=filled, done=list(done)):
+                with torch.cuda.stream(self.track_stream):
+                    self.track_stream.wait_event(filled)         # slots of this chunk are complete (eager path)
+                    for ev in done:
+                        self.track_stream.wait_event(ev)         # ... on every lane
+                    if release is not None:
+                        self.track_stream.wait_event(release)    # defer_tracking: the next frame's bottom-up pathway is through
+                    self.track(c)                                # SORT of chunk c runs under the detector pass of chunk c + 1
+                    if self.collate:
+                        self.rows.exchange(c)                    # (rows, births) all_gather + block gather, stream-ordered
+                    self._slot_done[c] = torch.cuda.Event()
+                    self._slot_done[c].record(self.track_stream)
+            if self.defer_tracking and self.use_graph:
+                self.flush()                                     # (never more than one call waiting)
+                self._pending_track = run_track
+            else:
+                run_track(None)
         if self.jpeg is not None:                                # who read this step's frame slots (before they are decoded into again)
             evs = list(done)
             ev = torch.cuda.Event()
@@ -344,6 +391,7 @@ class DetectTrackPipeline(object):
 def check_against(pipe, track_streams):
     """Replay the current segment's detections through `track_streams` (the CPU oracle's entry point, injected by the
     caller: tests / bench.py) and compare with what the GPU trackers produced.  Returns a small report dict."""
+    pipe.flush()
     packed, rows, births = pipe.history()
     p = pipe.track_params
     ref = track_streams(packed, p['max_age'], p['min_hits'], p['score_threshold'], p['iou_threshold'])
@@ -359,6 +407,7 @@ def collation_report(pipe, world, rank):
     rank numbers; on rank 0 the gathered block of rank 0 must equal its own rows and every rank's row count must equal the
     count that rank published."""
     import torch.distributed as dist
+    pipe.flush()
     rep = dict(collation='all_gather(rows, births) + one block gather per chunk, device-resident', exchanges=pipe.rows.exchanges)
     if dist.is_available() and dist.is_initialized():
         mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=pipe.dev)
@@ -446,10 +495,11 @@ def _pmc_traffic(tag):
 def run(args, world, rank, timed_steps):
     from .detnet.nn import ops
     fps = max(1, args.frames_per_step // 5)
-    pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False), n_inflight=getattr(args, 'inflight', 1))
+    track = args.stage == 'e2e'
+    pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False), n_inflight=getattr(args, 'inflight', 1),
+                               defer_tracking=track and not getattr(args, 'no_defer_track', False))
     steps = args.steps or 3
     warmup = args.warmup if args.warmup is not None else 1
-    track = args.stage == 'e2e'
     state = {'n': 0}
 
     def step():
@@ -461,6 +511,8 @@ def run(args, world, rank, timed_steps):
         # step share the chip with the SORT kernel of the previous chunk); the other frames replay the captured hipGraph of the
         # same launches
         pipe.step(track, instrument=ops.EVENT_LOG is not None)
+        if state['n'] in (warmup, warmup + steps):
+            pipe.flush()           # the SORT call that waits for the next frame belongs to the region that produced its detections
 
     # N > 1 (or --collate / WT_FORCE_DIST=1): behind every chunk's SORT the (rows, births) pairs of all ranks are exchanged
     # (all_gather: the id offsets of the sharded sequences) and the chunk's rows travel to rank 0 in ONE gather of the block as

@@ -201,12 +201,19 @@ class ResNeXt152FPN(nn.Module):
         self.output = nn.ModuleList([ConvBN(256, 256, 3, 1, 1, 1, gen, bias=True) for _ in STAGE_CH])
 
     def forward(self, x):
+        return self.top_down(self.bottom_up(x))
+
+    def bottom_up(self, x):
+        """stem .. res5 (the part of a frame that runs the persistent deformable-conv kernels)"""
         with torch.no_grad():                                # FREEZE_AT = 2: stem and res2 never train (job.log:219)
             x = self.stem(x, relu=True)
             x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
             c2 = self.res2(x)
         c3 = self.res3(c2); c4 = self.res4(c3); c5 = self.res5(c4)
-        feats = [c2, c3, c4, c5]
+        return [c2, c3, c4, c5]
+
+    def top_down(self, feats):
+        c5 = feats[3]
         prev = self.lateral[3](c5)
         outs = [self.output[3](prev)]
         for i in (2, 1, 0):                                  # top-down pathway, nearest x2, fuse "sum"
@@ -394,7 +401,11 @@ class CascadeRCNN(nn.Module):
     def forward_padded(self, x, img_h, img_w, proposals=None, intermediates=None):
         """The whole graph with static shapes and no host synchronisation (capturable as one hipGraph): returns
         (boxes (topk, 4), scores (topk), classes (topk) int64, count int32[1]); rows >= count are padding."""
-        feats = self.backbone(x)
+        return self.forward_padded_from(self.backbone.bottom_up(x), img_h, img_w, proposals, intermediates)
+
+    def forward_padded_from(self, bottom_up_feats, img_h, img_w, proposals=None, intermediates=None):
+        """forward_padded behind the bottom-up pathway: FPN top-down, RPN, cascade heads, static-shape tail."""
+        feats = self.backbone.top_down(bottom_up_feats)
         from_rpn = proposals is None
         if from_rpn:
             proposals, n_prop = self.rpn(feats, img_h, img_w)

@@ -112,6 +112,17 @@ class Detectron2Det(Module):
         self.last_input_size = (ho, wo)
         return self.model.forward_padded(xn, ho, wo)
 
+    def predict_padded_bottom_up(self, x, scale=1.0, hflip=False, vflip=False):
+        """First half of predict_padded: pre-processing + stem .. res5 -> [c2, c3, c4, c5] (static shapes)."""
+        xn, (ho, wo) = ops.preprocess(x, scale, hflip, vflip, True, PIXEL_MEAN, PIXEL_STD, 32)
+        self.last_input_size = (ho, wo)
+        return self.model.backbone.bottom_up(xn)
+
+    def predict_padded_heads(self, bottom_up_feats):
+        """Second half: FPN, RPN, cascade heads, tail - same outputs as predict_padded."""
+        ho, wo = self.last_input_size
+        return self.model.forward_padded_from(bottom_up_feats, ho, wo)
+
     def _predict_multiscale(self, x, scale, hflip, vflip, max_size=4000):
         """enable_tta(): GeneralizedRCNNWithTTA restated (detectron2 0.1.3 modeling/test_time_augmentation.py, FLIP False): one
         detector pass per min size (ResizeShortestEdge), boxes rescaled to the base image, all detections merged by the model's
