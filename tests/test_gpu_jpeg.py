@@ -61,6 +61,10 @@ def test_image_loader_decodes_jpeg_on_the_gpu(tmp_path):
         with open(path, 'wb') as f:
             f.write(JC.encode(JC.synth(h, w, 2, seed=i), quality=70 + 2 * i, subsampling=(2, 1, 0)[i % 3]))
         items.append((i, path))
+    prog = str(tmp_path / 'p.jpg')                                     # progressive: not decoded on the GPU -> PIL, announced once
+    with open(prog, 'wb') as f:
+        f.write(JC.encode(JC.synth(64, 80, 2, seed=77), quality=80, progressive=True))
+    items.append((98, prog))
     png = str(tmp_path / 'x.png')
     from PIL import Image
     Image.fromarray(JC.synth(40, 50, 0)).save(png)

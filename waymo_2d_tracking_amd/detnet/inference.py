@@ -25,6 +25,8 @@ import threading
 import numpy as np
 import torch
 
+from .. import _lib
+
 IMG_EXT = ('.jpg', '.jpeg', '.png', '.bmp')
 
 
@@ -159,6 +161,8 @@ def resize_size(w, h, size, max_size=None):
 
 
 class ImageLoader(object):
+    _warned = False
+
     """Decode ahead of the detector in a thread pool.  JPEG files: the file bytes go to the GPU and are decoded there
     (ops.jpeg_decode: Huffman, IDCT, upsampling, colour conversion in HIP kernels; bit-exact with PIL's decode, ~1 MB
     instead of 7.4 MB over PCIe per 1920x1280 frame).  With --resize, or for other formats: PIL decode + ToRGB (+ Resize,
@@ -201,9 +205,18 @@ class ImageLoader(object):
                 from .nn import ops
                 if getattr(self._local, 'stream', None) is None:
                     self._local.stream = torch.cuda.Stream()                        # one decode stream per loader thread
-                with torch.cuda.stream(self._local.stream):
-                    t = ops.jpeg_decode(data)                                       # returns with the image complete
-                return t, (t.shape[1], t.shape[0])
+                try:
+                    with torch.cuda.stream(self._local.stream):
+                        t = ops.jpeg_decode(data)                                   # returns with the image complete
+                    return t, (t.shape[1], t.shape[0])
+                except _lib.WaymoTrackError as e:
+                    # a flavour the HIP decoder does not implement (progressive, CMYK, ...) is read the way PNG / BMP files are:
+                    # by PIL, like the reference - said once, never silently; corrupt or truncated files still raise
+                    if 'unsupported' not in str(e):
+                        raise
+                    if not ImageLoader._warned:
+                        ImageLoader._warned = True
+                        print('ImageLoader: %s: %s -> such files are decoded by PIL on the host' % (path, e), flush=True)
         return self._decode_pil(path)
 
     def __iter__(self):
