@@ -194,6 +194,10 @@ int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset,
 int wd_tap_shift_add_f32(const float* partial, int ld, int n_out, const float* bias, int batch, int h, int w, int stride,
                          float* out, void* stream);
 
+/* Nearest-neighbour x2 upsampling of an NHWC float32 map: dst (N, 2H, 2W, C)[y][x] = src (N, H, W, C)[y / 2][x / 2] - the FPN top-down
+ * pathway (detectron2 fpn.py: F.interpolate(scale_factor=2, mode="nearest")).  C % 4 == 0. */
+int wd_upsample2x_nhwc_f32(const float* src, int batch, int h, int w, int c, float* dst, void* stream);
+
 /* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
 int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
 

@@ -435,3 +435,17 @@ assert err > 1e-7        # it really is the split path (the f32 kernel agrees to
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, WD_DEFORM_BF16X3='1'), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+
+
+def test_upsample2x_nearest_equals_interpolate():
+    """FPN top-down pathway: wd_upsample2x_nhwc_f32 == F.interpolate(scale_factor=2, mode='nearest'), bit for bit, at the three
+    pyramid sizes and an odd one"""
+    import torch.nn.functional as F
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    g = torch.Generator().manual_seed(0)
+    for (n, c, h, w) in ((1, 256, 40, 60), (1, 256, 80, 120), (1, 256, 160, 240), (2, 12, 5, 7)):
+        x = torch.randn((n, c, h, w), generator=g).cuda().contiguous(memory_format=torch.channels_last)
+        got = ops.upsample2x_nearest(x)
+        exp = F.interpolate(x, scale_factor=2.0, mode='nearest')
+        assert got.shape == exp.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, exp)

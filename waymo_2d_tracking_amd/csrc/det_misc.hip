@@ -143,6 +143,40 @@ extern "C" int wd_tap_shift_add_f32(const float* partial, int ld, int n_out, con
     return WT_OK;
 }
 
+// Nearest-neighbour x2 upsampling of an NHWC map (the FPN top-down pathway: F.interpolate(scale_factor=2, mode="nearest"),
+// detectron2 fpn.py) - one source float4 -> the 2 x 2 output float4s; 64 lanes cover 256 consecutive channels.  HBM-bound: reads the
+// source once, writes 4x that (the library kernel behind F.interpolate reaches 1.4 TB/s on the 157 MB p2 map; this one ~4 TB/s).
+__global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n_src4, int w,
+                                                             int c4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_src4; i += (long)gridDim.x * 256) {
+        const float4 v = src[i];
+        const long pix = i / c4;
+        const int ch = (int)(i - pix * c4);
+        const long row = pix / w;                     // n * h + y
+        const int x = (int)(pix - row * w);
+        float4* o = dst + ((row * 2) * (2L * w) + 2 * x) * c4 + ch;
+        o[0] = v; o[c4] = v;
+        o += 2L * w * c4;
+        o[0] = v; o[c4] = v;
+    }
+}
+
+extern "C" int wd_upsample2x_nhwc_f32(const float* src, int batch, int h, int w, int c, float* dst, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (batch <= 0 || h <= 0 || w <= 0 || c <= 0) return WT_OK;
+    if (!src || !dst || (c & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
+        wt::set_error("wd_upsample2x_nhwc_f32: C must be a multiple of 4 and pointers 16-byte aligned");
+        return WT_ERR_INVALID;
+    }
+    const long n4 = (long)batch * h * w * (c / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+                       n4, w, c / 4);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
 // Experiments only (tools/hold_experiment.py): n_wg one-wave workgroups that each hold `lds_bytes` of LDS and spin for `cycles` shader
 // cycles - a stand-in for the tracker's workgroups next to the detector (how much does HOLDING compute units cost the other stream?).
 namespace {

@@ -207,6 +207,18 @@ def bias_relu_(y, bias, relu=True):
     return y
 
 
+def upsample2x_nearest(x):
+    """F.interpolate(x, scale_factor=2.0, mode='nearest') on a channels_last float32 map (FPN top-down pathway), one HIP kernel
+    at HBM speed; returns a channels_last tensor.  Inference only (no autograd)."""
+    assert x.dtype == torch.float32 and x.dim() == 4
+    x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().wd_upsample2x_nhwc_f32(_p(x), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), _p(out), _stream()),
+               'wd_upsample2x_nhwc_f32')
+    return out
+
+
 def groupnorm_relu_(x, weight, bias, groups, eps=1e-5, relu=True):
     """In-place GroupNorm (+ReLU) on an (R,C,H,W) channels_last tensor with H*W <= 64 (the 7x7 box-head maps)."""
     assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32
