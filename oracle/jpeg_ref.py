@@ -69,6 +69,10 @@ def parse(data):
             out['comps'] = [dict(id=seg[6 + 3 * c], h=seg[7 + 3 * c] >> 4, v=seg[7 + 3 * c] & 15, tq=seg[8 + 3 * c]) for c in range(seg[5])]
         elif m in (0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
             raise Unsupported('SOF%d (progressive / lossless / arithmetic) is not baseline' % (m - 0xC0))
+        elif m == 0xE0 and seg[:5] == b'JFIF\x00':
+            out['jfif'] = True
+        elif m == 0xEE and seg[:5] == b'Adobe' and len(seg) >= 12:
+            out['adobe_transform'] = seg[11]
         elif m == 0xDD:
             out['restart_interval'] = (seg[0] << 8) | seg[1]
         elif m == 0xDA:
@@ -82,6 +86,9 @@ def parse(data):
             break
         pos += n
     out.update(qt=qt, dc=dc, ac=ac)
+    ids = [c['id'] for c in out['comps']]
+    if len(ids) == 3 and (out.get('adobe_transform') == 0 or ('adobe_transform' not in out and not out.get('jfif') and ids == [82, 71, 66])):
+        raise Unsupported('RGB-coded JPEG (no YCbCr transform; jdapimin.c default_decompress_parms)')
     # entropy-coded data: unstuff, cut at restart markers
     segs, cur = [], bytearray()
     while pos < len(data):

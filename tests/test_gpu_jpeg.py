@@ -65,6 +65,10 @@ def test_image_loader_decodes_jpeg_on_the_gpu(tmp_path):
     with open(prog, 'wb') as f:
         f.write(JC.encode(JC.synth(64, 80, 2, seed=77), quality=80, progressive=True))
     items.append((98, prog))
+    rgbj = str(tmp_path / 'r.jpg')                                     # RGB-coded samples (Adobe transform 0): PIL as well
+    with open(rgbj, 'wb') as f:
+        f.write(JC.encode(JC.synth(48, 40, 2, seed=78), quality=85, keep_rgb=True))
+    items.append((97, rgbj))
     png = str(tmp_path / 'x.png')
     from PIL import Image
     Image.fromarray(JC.synth(40, 50, 0)).save(png)

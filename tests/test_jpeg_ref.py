@@ -97,6 +97,12 @@ def test_header_parse_needs_no_gpu():
     prog = JC.encode(JC.synth(32, 32, 2), quality=80, progressive=True)
     assert lib.wd_jpeg_info(prog, ctypes.c_int64(len(prog)), *[ctypes.byref(v) for v in o]) != 0
     assert b'progressive' in lib.wt_last_error()
+    # samples stored as RGB (Adobe marker, transform 0): decoding them as YCbCr would give wrong colours without any error
+    rgb = JC.encode(JC.synth(32, 32, 2), quality=80, keep_rgb=True)
+    assert lib.wd_jpeg_info(rgb, ctypes.c_int64(len(rgb)), *[ctypes.byref(v) for v in o]) != 0
+    assert b'unsupported: RGB-coded' in lib.wt_last_error()
+    with pytest.raises(J.Unsupported):
+        J.decode_rgb(rgb)
 
 
 FUZZ = r'''

@@ -45,9 +45,10 @@ inline const char* parse(const uint8_t* d, size_t n, Parsed& out) {
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return ("not a JPEG file (no SOI)");
     memset(&out.hd, 0, sizeof(out.hd));
     Header& hd = out.hd;
+    bool have_jfif = false;
     bool have_sof = false, have_q[4] = {false, false, false, false}, have_h[4] = {false, false, false, false};
     int comp_id[4] = {0, 0, 0, 0};
-    int dri = 0;
+    int dri = 0, adobe_transform = -1;
     size_t pos = 2;
     for (;;) {
         while (pos < n && d[pos] != 0xFF) ++pos;
@@ -106,6 +107,11 @@ inline const char* parse(const uint8_t* d, size_t n, Parsed& out) {
             have_sof = true;
         } else if (m >= 0xC2 && m <= 0xCF && m != 0xC8 && m != 0xCC) {
             return ("unsupported: progressive / lossless / arithmetic-coded JPEG (only baseline Huffman is decoded on the GPU)");
+        } else if (m == 0xE0) {
+            if (sl >= 5 && memcmp(s, "JFIF", 5) == 0) have_jfif = true;
+        } else if (m == 0xEE) {
+            // Adobe APP14: transform 0 with three components = the samples are RGB, not YCbCr (jdapimin.c default_decompress_parms)
+            if (sl >= 12 && memcmp(s, "Adobe", 5) == 0) adobe_transform = s[11];
         } else if (m == 0xDD) {
             if (sl < 2) return ("bad DRI");
             dri = (s[0] << 8) | s[1];
@@ -134,6 +140,9 @@ inline const char* parse(const uint8_t* d, size_t n, Parsed& out) {
         hd.vmax = hd.comp_v[c] > hd.vmax ? hd.comp_v[c] : hd.vmax;
     }
     if (hd.ncomp == 3) {
+        // libjpeg's colour-space guess: Adobe transform 0, or (without JFIF / Adobe markers) component ids 'R' 'G' 'B'
+        if (adobe_transform == 0 || (adobe_transform < 0 && !have_jfif && comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B'))
+            return ("unsupported: RGB-coded JPEG (no YCbCr transform)");
         if (hd.comp_h[0] != hd.hmax || hd.comp_v[0] != hd.vmax || hd.comp_h[1] != hd.comp_h[2] || hd.comp_v[1] != hd.comp_v[2])
             return ("unsupported: luma is subsampled or the chroma planes differ");
         const int fh = hd.hmax / hd.comp_h[1], fv = hd.vmax / hd.comp_v[1];
