@@ -57,3 +57,21 @@ def medium_cases():
             kw['restart_marker_blocks'] = ri
         out.append(('%dx%d_s%d_q%d_r%d_k%d' % (h, w, sub, q, ri, kind), encode(synth(h, w, kind, seed=h), **kw)))
     return out
+
+
+def real_world_files(limit=16):
+    """JPEG files that ship with Python packages of this image (matplotlib, scikit-learn, scikit-image, ... sample data): written by
+    other encoders than PIL's - optimised Huffman tables, other quantisation tables, restart intervals, progressive ones.  The GPU box
+    runs the same image, so the same files exist there.  [] if none is found."""
+    import glob
+    pats = ['/usr/local/lib/python3*/dist-packages/*/datasets/images/*.jpg', '/usr/local/lib/python3*/dist-packages/matplotlib/mpl-data/sample_data/*.jpg',
+            '/opt/conda/lib/python3*/site-packages/skimage/data/*.jpg', '/opt/conda/lib/python3*/site-packages/*/static/images/*.jpg',
+            '/opt/conda/lib/python3*/site-packages/*/static/images/logos/*.jpg', '/opt/conda/lib/python3*/site-packages/nbconvert/tests/files/*.jpeg',
+            '/opt/conda/lib/python3*/site-packages/IPython/core/tests/*.jpg', '/opt/conda/doc/global/template/images/*.jpg',
+            '/usr/share/javascript/highlight.js/styles/*.jpg']
+    out = []
+    for p in pats:
+        for f in sorted(glob.glob(p)):
+            if f not in out:
+                out.append(f)
+    return out[:limit]

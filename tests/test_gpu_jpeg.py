@@ -78,3 +78,24 @@ def test_image_loader_decodes_jpeg_on_the_gpu(tmp_path):
     assert [g[0] for g in gpu] == [i for i, _ in items]
     for (ia, ta, sa), (ib, tb, sb) in zip(gpu, host):
         assert ia == ib and sa == sb and ta.dtype == torch.uint8 and torch.equal(ta.cpu(), tb.cpu())
+
+
+def test_decode_files_written_by_other_encoders():
+    """sample images that ship with the Python packages of the image (matplotlib, scikit-learn, scikit-image ...): other encoders,
+    optimised Huffman tables, a restart interval of 32, sizes up to 1411 x 1411 - bit-exact with PIL; progressive ones are refused"""
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    from waymo_2d_tracking_amd._lib import WaymoTrackError
+    files = JC.real_world_files()
+    if not files:
+        pytest.skip('no JPEG sample files on this machine')
+    decoded = 0
+    for f in files:
+        data = open(f, 'rb').read()
+        try:
+            got = ops.jpeg_decode(data)
+        except WaymoTrackError as e:
+            assert 'unsupported' in str(e), (f, str(e))
+            continue
+        assert np.array_equal(got.cpu().numpy(), JC.pil_rgb(data)), f
+        decoded += 1
+    assert decoded >= 1

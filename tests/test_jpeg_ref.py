@@ -105,6 +105,26 @@ def test_header_parse_needs_no_gpu():
         J.decode_rgb(rgb)
 
 
+def test_restatement_on_files_written_by_other_encoders():
+    """sample images shipped with the Python packages of this image (not PIL-encoded): the restatement equals PIL on every
+    baseline file (only the smaller ones: the Huffman stage of the restatement is a Python loop)"""
+    files = JC.real_world_files()
+    if not files:
+        pytest.skip('no JPEG sample files on this machine')
+    checked = 0
+    for f in files:
+        data = open(f, 'rb').read()
+        try:
+            info = J.parse(data)
+        except J.Unsupported:
+            continue
+        if info['width'] * info['height'] > 450 * 450:
+            continue
+        assert np.array_equal(J.decode_rgb(data), JC.pil_rgb(data)), f
+        checked += 1
+    assert checked >= 1
+
+
 FUZZ = r'''
 import sys, ctypes, numpy as np
 sys.path.insert(0, sys.argv[2])
