@@ -99,3 +99,40 @@ def test_decode_files_written_by_other_encoders():
         assert np.array_equal(got.cpu().numpy(), JC.pil_rgb(data)), f
         decoded += 1
     assert decoded >= 1
+
+
+def test_corrupt_files_raise_or_decode_but_never_break_the_device():
+    """300 mutated files (byte flips, truncation, header damage, insertions - the mutations of the CPU sanitizer run in
+    tests/test_jpeg_ref.py) through the GPU decoder: each call either returns an image of the announced size or raises
+    WaymoTrackError; afterwards the device still decodes a good file bit-exactly."""
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    from waymo_2d_tracking_amd._lib import WaymoTrackError
+    rng = np.random.default_rng(0)
+    seeds = [d for _, d in JC.small_cases()[:12]] + [JC.medium_cases()[0][1]]
+    ok = bad = 0
+    for it in range(300):
+        d = bytearray(seeds[it % len(seeds)])
+        mode = it % 4
+        if mode == 0:
+            for _ in range(rng.integers(1, 6)):
+                d[rng.integers(0, len(d))] = rng.integers(0, 256)
+        elif mode == 1:
+            d = d[:rng.integers(2, len(d))]
+        elif mode == 2:
+            d[rng.integers(0, min(len(d), 700))] = rng.integers(0, 256)
+        else:
+            i = rng.integers(0, len(d))
+            d[i:i] = bytes(rng.integers(0, 256, rng.integers(1, 8)).tolist())
+        try:
+            w, h = ops.jpeg_info(bytes(d))[:2]
+            if w * h > 4096 * 4096:
+                continue                                                # a damaged size field: not worth the memory
+            out = ops.jpeg_decode(bytes(d))
+            assert tuple(out.shape) == (h, w, 3)
+            ok += 1
+        except WaymoTrackError:
+            bad += 1
+    torch.cuda.synchronize()
+    assert ok > 0 and bad > 0
+    name, data = JC.medium_cases()[0]
+    assert np.array_equal(ops.jpeg_decode(data).cpu().numpy(), JC.pil_rgb(data))
