@@ -128,11 +128,12 @@ struct Counts {
 // Returns the exit state; `cnt` = blocks completed and the sum of the DC differences decoded, per component.
 // WRITE: coefficients go to coef[(block0 + completed) * 64 + natural position] as long as the block index stays below
 // block_end, DC as the running prediction that starts at pred0[component].
+// `nat` (WRITE): the zig-zag -> natural-order table in fast memory (LDS on the GPU), 80 entries; natural() otherwise.
 // The bit window lives in registers (64 bits, refilled one word at a time with the next word already in flight): one
 // dependent LDS access per symbol - the table lookup.
-template <bool WRITE, class WordPtr, class LutPtr>
+template <bool WRITE, class WordPtr, class LutPtr, class NatPtr = const uint8_t*>
 JD_HD State run(State st, uint32_t bound, uint32_t seg_end, WordPtr words, uint32_t w0, LutPtr luts, const Sel sel,
-                Counts& cnt, int16_t* __restrict__ coef, int block0, int block_end, const int32_t* pred0) {
+                Counts& cnt, int16_t* __restrict__ coef, int block0, int block_end, const int32_t* pred0, NatPtr nat = nullptr) {
     uint32_t p = st.p;
     int blk = (int)(st.bk >> 8), k = (int)(st.bk & 255);
     int n = 0, d0 = 0, d1 = 0, d2 = 0;
@@ -177,7 +178,7 @@ JD_HD State run(State st, uint32_t bound, uint32_t seg_end, WordPtr words, uint3
             const int r = sym >> 4;
             if (s) {
                 k += r;
-                if (WRITE && block0 + n < block_end) coef[(size_t)(block0 + n) * 64 + natural(k)] = (int16_t)extend(extra, s);
+                if (WRITE && block0 + n < block_end) coef[(size_t)(block0 + n) * 64 + (nat ? nat[k] : natural(k))] = (int16_t)extend(extra, s);
                 ++k;
             } else if (r == 15) {
                 k += 16;
@@ -196,6 +197,28 @@ JD_HD State run(State st, uint32_t bound, uint32_t seg_end, WordPtr words, uint3
     out.p = p;
     out.bk = ((uint32_t)blk << 8) | (uint32_t)k;
     return out;
+}
+
+// ---- candidate sets (jpeg_cand_kernel / jpeg_resolve_kernel) -----------------------------------------------------------------
+// The iteration "decode from the predecessor's exit until nothing changes" moves the truth one subsequence per pass through every
+// stretch of subsequences that did not fall into step on their own - 12 to 14 passes on a 4:2:0 frame, because a stream needs the
+// block-in-MCU index (Y Y Y Y Cb Cr use different tables) to line up as well, and a single guess achieves that in 53 % of the
+// subsequences only.  But the true exit is AMONG the exits of the guesses "block index h at my first bit" in 97 % of them.  So
+// every subsequence keeps a small set of candidate (start state -> exit state) decodes: first the block-index guesses, then, launch
+// by launch, every exit of its predecessor's candidates that it has not started from yet.  After three such launches the sets are
+// closed on a photo-like frame (every candidate exit of i - 1 is a candidate start of i), the true chain is a path through them,
+// and which candidate it is in every subsequence follows from a segmented scan over index maps (composition of maps is
+// associative).  Streams that do not fall into step inside one subsequence (quality-100 noise) leave the chain unresolved; the
+// plain iteration and the chain check behind it remain the judge in every case.
+constexpr int CAND_MAX = 12;                       // candidates per subsequence
+constexpr int CAND_SLOTS = 8;                      // threads per subsequence in jpeg_cand_kernel (>= blocks per MCU of the supported files)
+constexpr uint32_t CAND_NONE = 15;
+JD_HD uint64_t map_identity() { return 0xFEDCBA9876543210ull; }
+JD_HD uint32_t map_at(uint64_t m, uint32_t x) { return (uint32_t)(m >> (4 * x)) & 15u; }
+JD_HD uint64_t map_compose(uint64_t later, uint64_t earlier) {               // x -> later[earlier[x]]; CAND_NONE stays CAND_NONE
+    uint64_t r = 0;
+    for (int x = 0; x < 16; ++x) r |= (uint64_t)map_at(later, map_at(earlier, (uint32_t)x)) << (4 * x);
+    return r;
 }
 
 }  // namespace jd

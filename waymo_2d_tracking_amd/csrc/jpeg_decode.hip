@@ -1,7 +1,10 @@
 // GPU JPEG decode - see jpeg_core.h for the scheme.  One call = one image:
 //   host   : marker parse, Huffman / quantisation tables, byte unstuffing into restart segments (a memchr pass), one
 //            pinned staging blob -> ONE hipMemcpyAsync
-//   device : jpeg_sync_kernel (x3)  - subsequence synchronisation, bitstream + tables in LDS
+//   device : jpeg_cand_kernel (x4), jpeg_resolve_kernel - candidate (start -> exit) decodes per subsequence and the true chain
+//                                     through them by a scan over index maps (jpeg_core.h)
+//            jpeg_sync_kernel (x2)  - subsequence synchronisation by iteration (settles what the candidates left open; a
+//                                     no-op pass otherwise), bitstream + tables in LDS
 //            jpeg_scan_kernel       - chain check + first block index / DC predictions of every subsequence (segmented scan)
 //            jpeg_write_kernel      - final decode pass, coefficients (int16, natural order, DC resolved) to HBM
 //            jpeg_idct_kernel       - dequantise + jidctint.c islow, 8 threads per block, planes in u8
@@ -44,6 +47,12 @@ struct Dev {                         // device pointers into the blob + work buf
     const uint32_t* stream;          // bytes as stored (big-endian bit order): words are byte-swapped on load
     int4* cnt;                       // per subsequence: blocks completed, DC differences summed per component
     int4* base;                      // per subsequence: first block index, DC predictions at its start
+    State* cand_s;                   // [subsequence][CAND_MAX]: candidate start states ...
+    State* cand_e;                   // ... their exit states ...
+    int4* cand_c;                    // ... and counts
+    int32_t* cand_n;                 // [3][subsequence]: number of candidates after launch l in buffer l % 3
+    unsigned long long* cand_map;    // [subsequence]: candidate index of i - 1 -> candidate index of i (4 bits each)
+    uint8_t* cand_pick;              // [subsequence]: index of the candidate on the true chain (CAND_NONE = unresolved)
     int16_t* coef;
     uint8_t* planes;
     int32_t* flags;                  // [0] chain not settled, [1] a segment came up short, [2] / [3] statistics
@@ -68,6 +77,16 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kSyncThreads + tid;
     const bool valid = i < d.nsub;
+    {   // nothing to do for this workgroup (the usual case behind the candidate sets)?  Then leave before staging 66 KB.
+        int need = 0;
+        if (valid) {
+            const int sg = d.sub_seg[i];
+            State want;
+            if (d.seg_first_sub[sg] == (uint32_t)i) { want.p = (uint32_t)i * jd::SUB_BITS; want.bk = 0; } else want = d.exit[i - 1];
+            need = !jd::same(want, d.start[i]);
+        }
+        if (!__syncthreads_or(need)) return;
+    }
     stage(d, words, luts);
     const jd::Sel sel = jd::make_sel(d.hd);
     const uint32_t w0 = blockIdx.x * (uint32_t)(kSyncThreads * jd::SUB_WORDS);
@@ -114,6 +133,180 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_sync_kernel(Dev d) {
     // statistics (wd_jpeg_last_stats): longest iteration count of a workgroup, subsequence decodes in total
     if (tid == 0) atomicMax(&d.flags[2], iters);
     if (decodes) atomicAdd(&d.flags[3], decodes);
+}
+
+constexpr int kCandSubs = kSyncThreads / jd::CAND_SLOTS;                 // subsequences per workgroup of jpeg_cand_kernel
+constexpr int kCandWords = kCandSubs * jd::SUB_WORDS + 4;
+
+// Candidate sets, one launch = one round (jpeg_core.h).  CAND_SLOTS threads per subsequence.  launch 0: slot h decodes from
+// (first bit, block index h, DC next); later launches: slot r decodes from the r-th exit of the predecessor's candidates (as of the
+// previous launch) that is not yet among this subsequence's starts.  Records are append-only; counts are double-buffered.
+__global__ __launch_bounds__(kSyncThreads) void jpeg_cand_kernel(Dev d, int launch) {
+    __shared__ uint32_t words[kCandWords];
+    __shared__ HuffLut luts[4];
+    const int tid = threadIdx.x, slot = tid % jd::CAND_SLOTS;
+    const int i = blockIdx.x * kCandSubs + tid / jd::CAND_SLOTS;
+    const uint32_t w0 = blockIdx.x * (uint32_t)(kCandSubs * jd::SUB_WORDS);
+    const jd::Sel sel = jd::make_sel(d.hd);
+    // what does this thread decode?  (decided from global memory first: in the later launches most workgroups have nothing to do
+    // and leave before staging their 38 KB of bitstream and tables)
+    State s{jd::NO_STATE, jd::NO_STATE};
+    int at = -1;
+    uint32_t seg_end = 0, bound = 0;
+    if (i < d.nsub) {
+        const int seg = d.sub_seg[i];
+        const bool first = d.seg_first_sub[seg] == (uint32_t)i;
+        seg_end = d.seg_end_bit[seg];
+        bound = (uint32_t)(i + 1) * jd::SUB_BITS;
+        bound = bound < seg_end ? bound : seg_end;
+        int32_t* n_new = d.cand_n + (size_t)(launch % 3) * d.nsub;
+        const int32_t* n_old = d.cand_n + (size_t)((launch + 2) % 3) * d.nsub;
+        const int32_t* n_old2 = d.cand_n + (size_t)((launch + 1) % 3) * d.nsub;
+        if (launch == 0) {
+            const int n = first ? 1 : sel.bpm;
+            if (slot == 0) n_new[i] = n;
+            if (slot < n) { s.p = (uint32_t)i * jd::SUB_BITS; s.bk = first ? 0u : (uint32_t)slot << 8; at = slot; }
+        } else {
+            const int mine = n_old[i];
+            int fresh = 0;
+            if (!first) {
+                const int theirs = n_old[i - 1], seen = launch >= 2 ? n_old2[i - 1] : 0;      // [seen, theirs): added by the previous launch
+                if (theirs > seen) {
+                    const State* pe = d.cand_e + (size_t)(i - 1) * jd::CAND_MAX;
+                    const State* my_s = d.cand_s + (size_t)i * jd::CAND_MAX;
+                    for (int a = seen; a < theirs; ++a) {
+                        const State e = pe[a];
+                        bool known = e.p == jd::NO_STATE;
+                        for (int b = 0; b < mine; ++b) known |= jd::same(my_s[b], e);
+                        for (int b = seen; b < a; ++b) known |= jd::same(pe[b], e);        // the same exit twice among the new ones
+                        if (known) continue;
+                        if (fresh == slot && mine + fresh < jd::CAND_MAX) { s = e; at = mine + fresh; }
+                        ++fresh;
+                    }
+                }
+            }
+            fresh = fresh < jd::CAND_SLOTS ? fresh : jd::CAND_SLOTS;         // one decode per slot and launch
+            if (slot == 0) n_new[i] = mine + fresh < jd::CAND_MAX ? mine + fresh : jd::CAND_MAX;
+        }
+        if (at >= 0 && (s.p < w0 * 32u || s.p > bound)) {                   // cannot be decoded from this workgroup's window: an empty record
+            d.cand_s[(size_t)i * jd::CAND_MAX + at] = State{jd::NO_STATE, jd::NO_STATE};
+            d.cand_e[(size_t)i * jd::CAND_MAX + at] = State{jd::NO_STATE, jd::NO_STATE};
+            at = -1;
+        }
+    }
+    if (!__syncthreads_or(at >= 0 ? 1 : 0)) return;
+    for (int j = tid; j < kCandWords; j += kSyncThreads) {
+        const uint32_t g = w0 + (uint32_t)j;
+        words[j] = g < (uint32_t)d.stream_words ? __builtin_bswap32(d.stream[g]) : 0xFFFFFFFFu;
+    }
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(d.luts);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(luts);
+        for (int j = tid; j < (int)(4 * sizeof(HuffLut) / 4); j += kSyncThreads) dst[j] = src[j];
+    }
+    __syncthreads();
+    if (at < 0) return;
+    jd::Counts c{0, {0, 0, 0}};
+    const State e = jd::run<false>(s, bound, seg_end, words, w0, luts, sel, c, nullptr, 0, 0, nullptr);
+    d.cand_s[(size_t)i * jd::CAND_MAX + at] = s;
+    d.cand_e[(size_t)i * jd::CAND_MAX + at] = e;
+    d.cand_c[(size_t)i * jd::CAND_MAX + at] = make_int4(c.n, c.dc[0], c.dc[1], c.dc[2]);
+}
+
+// map of the link i - 1 -> i: candidate a of i - 1 -> the candidate of i that starts at a's exit (CAND_NONE if there is none)
+__global__ __launch_bounds__(256) void jpeg_map_kernel(Dev d, int parity) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nsub) return;
+    const int32_t* cn = d.cand_n + (size_t)parity * d.nsub;
+    uint64_t mm = jd::map_identity();
+    if (d.seg_first_sub[d.sub_seg[i]] != (uint32_t)i) {
+        const int theirs = cn[i - 1], mine = cn[i];
+        State ms[jd::CAND_MAX];
+#pragma unroll
+        for (int b = 0; b < jd::CAND_MAX; ++b) ms[b] = b < mine ? d.cand_s[(size_t)i * jd::CAND_MAX + b] : State{jd::NO_STATE, jd::NO_STATE};
+        mm = (uint64_t)jd::CAND_NONE << 60;                                   // CAND_NONE -> CAND_NONE
+#pragma unroll
+        for (int a = 0; a < 15; ++a) {
+            uint32_t to = jd::CAND_NONE;
+            if (a < theirs && a < jd::CAND_MAX) {
+                const State e = d.cand_e[(size_t)(i - 1) * jd::CAND_MAX + a];
+#pragma unroll
+                for (int b = 0; b < jd::CAND_MAX; ++b) to = (e.p != jd::NO_STATE && jd::same(ms[b], e)) ? (uint32_t)b : to;
+            }
+            mm |= (uint64_t)to << (4 * a);
+        }
+    }
+    d.cand_map[i] = mm;
+}
+
+// one workgroup: which candidate of every subsequence lies on the true chain?  A segment's first subsequence has one candidate,
+// index 0; segmented scan over the link maps (composition), then start / exit / counts of every resolved subsequence are copied
+// from its candidate.
+__global__ __launch_bounds__(1024) void jpeg_resolve_kernel(Dev d) {
+    constexpr int ITEMS = 8;
+    __shared__ uint64_t maps[1024];
+    __shared__ int flgs[1024];
+    __shared__ uint64_t carry_s;
+    const int tid = threadIdx.x, nsub = d.nsub;
+    if (tid == 0) carry_s = jd::map_identity();
+    __syncthreads();
+    for (int c0 = 0; c0 < nsub; c0 += 1024 * ITEMS) {
+        uint64_t m[ITEMS];
+        int firsts = 0, any = 0;
+        uint64_t total = jd::map_identity();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int i = c0 + tid * ITEMS + j;
+            m[j] = jd::map_identity();
+            if (i < nsub) {
+                const int f = d.seg_first_sub[d.sub_seg[i]] == (uint32_t)i;
+                firsts |= f << j;
+                m[j] = d.cand_map[i];
+                total = f ? jd::map_identity() : jd::map_compose(m[j], total);
+                any |= f;
+            }
+        }
+        maps[tid] = total;
+        flgs[tid] = any;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint64_t a = maps[tid];
+            int g = flgs[tid];
+            if (tid >= off && !g) { a = jd::map_compose(a, maps[tid - off]); g = flgs[tid - off]; }
+            __syncthreads();
+            maps[tid] = a;
+            flgs[tid] = g;
+            __syncthreads();
+        }
+        const uint64_t chunk = carry_s;
+        // candidate index of the subsequence in front of this thread's first item (0 at a segment start)
+        uint32_t b = jd::map_at(chunk, 0);
+        if (tid > 0) b = flgs[tid - 1] ? jd::map_at(maps[tid - 1], 0) : jd::map_at(maps[tid - 1], jd::map_at(chunk, 0));
+        const uint64_t last = flgs[1023] ? maps[1023] : jd::map_compose(maps[1023], chunk);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int i = c0 + tid * ITEMS + j;
+            if (i >= nsub) continue;
+            b = ((firsts >> j) & 1) ? 0u : jd::map_at(m[j], b);
+            d.cand_pick[i] = (uint8_t)b;
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = last;
+        __syncthreads();
+    }
+}
+
+// start / exit / counts of every resolved subsequence = its candidate on the true chain
+__global__ __launch_bounds__(256) void jpeg_pick_kernel(Dev d, int parity) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nsub) return;
+    const uint32_t b = d.cand_pick[i];
+    if (b == jd::CAND_NONE || (int)b >= d.cand_n[(size_t)parity * d.nsub + i]) return;
+    const State s = d.cand_s[(size_t)i * jd::CAND_MAX + b];
+    if (s.p == jd::NO_STATE) return;
+    d.start[i] = s;
+    d.exit[i] = d.cand_e[(size_t)i * jd::CAND_MAX + b];
+    d.cnt[i] = d.cand_c[(size_t)i * jd::CAND_MAX + b];
 }
 
 // one workgroup: is every start state the exit state of its predecessor (or the known segment start)?  Running values of
@@ -199,9 +392,11 @@ __global__ __launch_bounds__(1024) void jpeg_scan_kernel(Dev d) {
 __global__ __launch_bounds__(kSyncThreads) void jpeg_write_kernel(Dev d) {
     __shared__ uint32_t words[kLdsWords];
     __shared__ HuffLut luts[4];
+    __shared__ uint8_t nat[80];                      // zig-zag -> natural order next to the stream (a constant-memory load per coefficient otherwise)
     const int tid = threadIdx.x;
     const int i = blockIdx.x * kSyncThreads + tid;
     stage(d, words, luts);
+    if (tid < 80) nat[tid] = (uint8_t)jd::natural(tid);
     const jd::Sel sel = jd::make_sel(d.hd);
     __syncthreads();
     if (i >= d.nsub) return;
@@ -219,7 +414,7 @@ __global__ __launch_bounds__(kSyncThreads) void jpeg_write_kernel(Dev d) {
     const int4 b = d.base[i];
     const int32_t pred[3] = {b.y, b.z, b.w};
     jd::Counts c;
-    (void)jd::run<true>(s, bound, seg_end, words, w0, luts, sel, c, d.coef, b.x, block_end, pred);
+    (void)jd::run<true>(s, bound, seg_end, words, w0, luts, sel, c, d.coef, b.x, block_end, pred, (const uint8_t*)nat);
 }
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -481,6 +676,10 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
     size_t woff = 0;
     auto take = [&](size_t b) { const size_t o = woff; woff += wt::align_up(b); return o; };
     const size_t o_cnt = take((size_t)L.max_sub * 16), o_base = take((size_t)L.max_sub * 16), o_flags = take(64);
+    const size_t o_cn = take((size_t)L.max_sub * 12);
+    const size_t o_zero_end = woff;                      // everything up to here is zeroed per call
+    const size_t o_cs = take((size_t)L.max_sub * jd::CAND_MAX * sizeof(State)), o_ce = take((size_t)L.max_sub * jd::CAND_MAX * sizeof(State));
+    const size_t o_cc = take((size_t)L.max_sub * jd::CAND_MAX * 16), o_cm = take((size_t)L.max_sub * 8), o_cp = take((size_t)L.max_sub);
     const size_t o_coef = take((size_t)hd.total_blocks * 128), o_planes = take(planes_bytes);
     Ctx* ctx = acquire();
     Release rel{ctx};
@@ -491,7 +690,8 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t used = L.stream + (size_t)hd.nsub * jd::SUB_BYTES + 16;
     WT_HIP(hipMemcpyAsync(ctx->dev, ctx->host, used, hipMemcpyHostToDevice, st));
-    WT_HIP(hipMemsetAsync(ctx->work, 0, o_coef + (size_t)hd.total_blocks * 128, st));       // nblk, base, flags, coefficients
+    WT_HIP(hipMemsetAsync(ctx->work, 0, o_zero_end, st));                                    // counts, bases, flags, candidate counts
+    WT_HIP(hipMemsetAsync(ctx->work + o_coef, 0, (size_t)hd.total_blocks * 128, st));        // coefficients
     Dev d;
     d.hd = reinterpret_cast<const Header*>(ctx->dev + L.header);
     d.luts = reinterpret_cast<const HuffLut*>(ctx->dev + L.luts);
@@ -504,6 +704,12 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
     d.cnt = reinterpret_cast<int4*>(ctx->work + o_cnt);
     d.base = reinterpret_cast<int4*>(ctx->work + o_base);
     d.flags = reinterpret_cast<int32_t*>(ctx->work + o_flags);
+    d.cand_n = reinterpret_cast<int32_t*>(ctx->work + o_cn);
+    d.cand_s = reinterpret_cast<State*>(ctx->work + o_cs);
+    d.cand_e = reinterpret_cast<State*>(ctx->work + o_ce);
+    d.cand_c = reinterpret_cast<int4*>(ctx->work + o_cc);
+    d.cand_map = reinterpret_cast<unsigned long long*>(ctx->work + o_cm);
+    d.cand_pick = ctx->work + o_cp;
     d.coef = reinterpret_cast<int16_t*>(ctx->work + o_coef);
     d.planes = ctx->work + o_planes;
     d.nsub = hd.nsub;
@@ -525,7 +731,16 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
         WT_HIP(hipStreamSynchronize(st));
         return WT_OK;
     };
-    for (; rounds < 3; ++rounds) hipLaunchKernelGGL(jpeg_sync_kernel, dim3(sync_grid), dim3(kSyncThreads), 0, st, d);
+    // candidate sets: block-index guesses, three closure launches, the true chain by a scan over index maps; then the plain
+    // iteration (a no-op pass when the chain is already consistent) and the chain check
+    const unsigned cand_grid = (unsigned)((hd.nsub + kCandSubs - 1) / kCandSubs);
+    constexpr int kCandLaunches = 4;
+    for (int l = 0; l < kCandLaunches; ++l) hipLaunchKernelGGL(jpeg_cand_kernel, dim3(cand_grid), dim3(kSyncThreads), 0, st, d, l);
+    const unsigned per_sub_grid = (unsigned)((hd.nsub + 255) / 256);
+    hipLaunchKernelGGL(jpeg_map_kernel, dim3(per_sub_grid), dim3(256), 0, st, d, (kCandLaunches - 1) % 3);
+    hipLaunchKernelGGL(jpeg_resolve_kernel, dim3(1), dim3(1024), 0, st, d);
+    hipLaunchKernelGGL(jpeg_pick_kernel, dim3(per_sub_grid), dim3(256), 0, st, d, (kCandLaunches - 1) % 3);
+    for (; rounds < 2; ++rounds) hipLaunchKernelGGL(jpeg_sync_kernel, dim3(sync_grid), dim3(kSyncThreads), 0, st, d);
     WT_TRY(tail());
     while (ctx->host_flags[0]) {                      // chain not settled yet: more rounds, then the tail again
         if (rounds > hd.nsub + 3) return fail("internal: subsequence chain did not settle");
