@@ -204,11 +204,12 @@ int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void*
 /* GPU JPEG decode: replaces `PIL.Image.open(path).convert('RGB')` of the reference's loader
  * (detnet/data/coco.py image read + detnet/inference.py:170 ToRGB), i.e. libjpeg-turbo at its defaults (baseline Huffman,
  * JDCT_ISLOW, fancy upsampling, jdcolor YCbCr -> RGB); bit-exact with it.  Entropy decoding runs on the GPU by
- * self-synchronising 1024-bit subsequences (csrc/jpeg_core.h); only marker parsing and byte unstuffing stay on the host.
+ * self-synchronising 1024-bit subsequences with candidate sets (csrc/jpeg_core.h); only marker parsing and byte unstuffing stay on the host.
  *   data / n   : HOST pointer to the file bytes
  *   rgb        : DEVICE buffer of `capacity` bytes, receives (height, width, 3) uint8 RGB (grayscale files replicated,
  *                as convert('RGB') does) - the layout wd_preprocess_f32 takes as WD_LAYOUT_NHWC_U8
- *   sync_rounds: optional, number of synchronisation launches it took (3 unless the stream is adversarial)
+ *   sync_rounds: optional, number of iteration launches behind the candidate sets (2 unless the stream does not synchronise
+ *                inside a subsequence, e.g. quality-100 noise)
  * The call returns when the image is complete (it synchronises `stream`).  Supported: 8-bit baseline / extended
  * sequential Huffman, one interleaved scan, grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals.  Anything else
  * (progressive, arithmetic, CMYK, multi-scan, truncated data) is WT_ERR_INVALID with the reason in wt_last_error().
