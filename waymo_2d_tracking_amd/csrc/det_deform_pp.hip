@@ -29,6 +29,7 @@
 // LDS (32 channels per group): 24 576 (weights of 6 taps) + 4 x 25 216 (patches) + 4 x 9 216 (tables) = 162 304 bytes.
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 #include <type_traits>
 #include "common.h"
 #include "../../include/waymodet.h"
@@ -643,28 +644,33 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
 }  // namespace
 
 // scratch table for callers that pass offsets without a pre-built table (stride-2 layers, tests, tools, the training forward): grown on
-// demand, one process = one GPU.  A buffer that has been handed out may be baked into a captured hipGraph, so it is never freed or moved:
-// growing allocates a NEW buffer and keeps the old one alive (a few MB per distinct size class, once).
+// demand, ONE BUFFER PER STREAM - launches on different streams may be in flight together (two detector instances of one process), and
+// the table is written by one launch and read by the next on the same stream only.  A buffer that has been handed out may be baked
+// into a captured hipGraph, so it is never freed or moved: growing allocates a NEW buffer and keeps the old one alive (a few MB per
+// distinct size class and stream, once).
 static int scratch_table(size_t bytes, hipStream_t stream, void** out) {
+    struct Slot { hipStream_t stream; void* buf; size_t cap; };
     static std::mutex mu;
-    static void* buf = nullptr;
-    static size_t cap = 0;
+    static std::vector<Slot> slots;
     std::lock_guard<std::mutex> lock(mu);
-    if (bytes > cap) {
+    Slot* sl = nullptr;
+    for (Slot& c : slots) if (c.stream == stream) sl = &c;
+    if (!sl) { slots.push_back(Slot{stream, nullptr, 0}); sl = &slots.back(); }
+    if (bytes > sl->cap) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &st);
         if (st != hipStreamCaptureStatusNone) {
-            wt::set_error("wd_deform_conv3x3: the sampling-table scratch must grow inside a stream capture; run the shape once eagerly "
-                          "or pass a table (wd_deform_offsets_table_f32)");
+            wt::set_error("wd_deform_conv3x3: the sampling-table scratch must grow inside a stream capture; run the shape once eagerly on "
+                          "this stream or pass a table (wd_deform_offsets_table_f32)");
             return WT_ERR_INVALID;
         }
         void* fresh = nullptr;
         const size_t want = bytes + bytes / 4;                   // head room: fewer size classes
         WT_HIP(hipMalloc(&fresh, want));
-        buf = fresh;                                             // the previous buffer stays allocated (see above)
-        cap = want;
+        sl->buf = fresh;                                         // the previous buffer stays allocated (see above)
+        sl->cap = want;
     }
-    *out = buf;
+    *out = sl->buf;
     return WT_OK;
 }
 
