@@ -1,8 +1,8 @@
 // GPU JPEG decode - see jpeg_core.h for the scheme.  One call = one image:
 //   host   : marker parse, Huffman / quantisation tables, byte unstuffing into restart segments (a memchr pass), one
 //            pinned staging blob -> ONE hipMemcpyAsync
-//   device : jpeg_cand_kernel (x4), jpeg_resolve_kernel - candidate (start -> exit) decodes per subsequence and the true chain
-//                                     through them by a scan over index maps (jpeg_core.h)
+//   device : jpeg_cand_kernel (x4), jpeg_map_kernel, jpeg_resolve_kernel, jpeg_pick_kernel - candidate (start -> exit) decodes
+//                                     per subsequence and the true chain through them by a scan over index maps (jpeg_core.h)
 //            jpeg_sync_kernel (x2)  - subsequence synchronisation by iteration (settles what the candidates left open; a
 //                                     no-op pass otherwise), bitstream + tables in LDS
 //            jpeg_scan_kernel       - chain check + first block index / DC predictions of every subsequence (segmented scan)
@@ -10,7 +10,7 @@
 //            jpeg_idct_kernel       - dequantise + jidctint.c islow, 8 threads per block, planes in u8
 //            jpeg_color_kernel      - fancy h2v1 / h2v2 upsampling + YCbCr -> RGB, (H, W, 3) u8 out
 // The call returns after its stream has drained (it has to read the "chain settled" flag); when the flag is not set
-// after three rounds (adversarial streams) it keeps launching sync rounds until it is and repeats the tail.
+// (streams that do not synchronise inside a subsequence) it keeps launching sync rounds until it is and repeats the tail.
 #include <mutex>
 #include <vector>
 #include "common.h"
