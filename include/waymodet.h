@@ -201,6 +201,12 @@ int wd_upsample2x_nhwc_f32(const float* src, int batch, int h, int w, int c, flo
 /* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
 int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
 
+/* ImageOps.autocontrast(image) of PIL with cutoff 0 - the reference's AutoContrast transform (detnet/trainer/transforms/vision.py:1069-1075,
+ * detnet/inference.py:171; README.md:37 runs with --auto-contrast=1) - on an (h, w, 3) uint8 DEVICE image, in place, bit-exact with PIL
+ * (per channel lut[v] = clamp(int(v * (255.0 / (hi - lo)) + (-lo * scale)), 0, 255) in float64, identity when hi <= lo).
+ * workspace24: 24 bytes of device memory (min / max of the three channels). */
+int wd_autocontrast_u8(uint8_t* img, int h, int w, void* workspace24, void* stream);
+
 /* GPU JPEG decode: replaces `PIL.Image.open(path).convert('RGB')` of the reference's loader
  * (detnet/data/coco.py image read + detnet/inference.py:170 ToRGB), i.e. libjpeg-turbo at its defaults (baseline Huffman,
  * JDCT_ISLOW, fancy upsampling, jdcolor YCbCr -> RGB); bit-exact with it.  Entropy decoding runs on the GPU by

@@ -121,6 +121,83 @@ extern "C" int wd_preprocess_out_shape(int h, int w, double scale, int divisor, 
     return WT_OK;
 }
 
+// ImageOps.autocontrast(image) of PIL with cutoff 0 (the reference's AutoContrast transform, trainer/transforms/vision.py:1069-1075;
+// README.md:37 runs the detector with --auto-contrast=1) on an (H, W, 3) uint8 image, in place.  Per channel: lo / hi = darkest /
+// brightest value present; hi <= lo: unchanged; else lut[v] = clamp(int(v * scale + offset), 0, 255) with scale = 255.0 / (hi - lo),
+// offset = -lo * scale in Python floats: four separately rounded float64 operations (this unit is compiled with -ffp-contract=off).
+// Two launches: min / max by wave reduction + 6 atomics per wave, then every workgroup builds the 3 x 256 table in LDS and maps.
+__global__ __launch_bounds__(256) void autocontrast_minmax_kernel(const uint8_t* __restrict__ img, long n_pix, unsigned* __restrict__ mm) {
+    unsigned lo[3] = {255u, 255u, 255u}, hi[3] = {0u, 0u, 0u};
+    const long n4 = n_pix / 4;                                  // 4 pixels = 12 bytes = 3 words
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(img);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const uint32_t a = w[3 * i], b = w[3 * i + 1], c = w[3 * i + 2];
+        const unsigned px[12] = {a & 255u, (a >> 8) & 255u, (a >> 16) & 255u, a >> 24, b & 255u, (b >> 8) & 255u, (b >> 16) & 255u, b >> 24,
+                                 c & 255u, (c >> 8) & 255u, (c >> 16) & 255u, c >> 24};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { lo[k % 3] = min(lo[k % 3], px[k]); hi[k % 3] = max(hi[k % 3], px[k]); }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long p = n4 * 4; p < n_pix; ++p)
+            for (int c = 0; c < 3; ++c) { lo[c] = min(lo[c], (unsigned)img[3 * p + c]); hi[c] = max(hi[c], (unsigned)img[3 * p + c]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[c] = min(lo[c], (unsigned)__shfl_xor((int)lo[c], off));
+            hi[c] = max(hi[c], (unsigned)__shfl_xor((int)hi[c], off));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&mm[c], lo[c]); atomicMax(&mm[3 + c], hi[c]); }
+    }
+}
+
+__global__ __launch_bounds__(256) void autocontrast_apply_kernel(uint8_t* __restrict__ img, long n_pix, const unsigned* __restrict__ mm) {
+    __shared__ uint8_t lut[3][256];
+    for (int t = threadIdx.x; t < 768; t += 256) {
+        const int c = t >> 8, v = t & 255;
+        const int lo = (int)mm[c], hi = (int)mm[3 + c];
+        int o = v;
+        if (hi > lo) {
+            const double scale = 255.0 / (double)(hi - lo);
+            const double offset = (double)(-lo) * scale;
+            const double x = (double)v * scale + offset;        // two roundings (no FMA contraction in this unit)
+            o = (int)x;
+            o = o < 0 ? 0 : (o > 255 ? 255 : o);
+        }
+        lut[c][v] = (uint8_t)o;
+    }
+    __syncthreads();
+    const long n4 = n_pix / 4;
+    uint32_t* w = reinterpret_cast<uint32_t*>(img);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        uint32_t a = w[3 * i], b = w[3 * i + 1], c = w[3 * i + 2];
+        a = lut[0][a & 255u] | (lut[1][(a >> 8) & 255u] << 8) | (lut[2][(a >> 16) & 255u] << 16) | ((uint32_t)lut[0][a >> 24] << 24);
+        b = lut[1][b & 255u] | (lut[2][(b >> 8) & 255u] << 8) | (lut[0][(b >> 16) & 255u] << 16) | ((uint32_t)lut[1][b >> 24] << 24);
+        c = lut[2][c & 255u] | (lut[0][(c >> 8) & 255u] << 8) | (lut[1][(c >> 16) & 255u] << 16) | ((uint32_t)lut[2][c >> 24] << 24);
+        w[3 * i] = a; w[3 * i + 1] = b; w[3 * i + 2] = c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long p = n4 * 4; p < n_pix; ++p)
+            for (int c = 0; c < 3; ++c) img[3 * p + c] = lut[c][img[3 * p + c]];
+}
+
+extern "C" int wd_autocontrast_u8(uint8_t* img, int h, int w, void* workspace24, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (!img || !workspace24 || h < 1 || w < 1 || ((uintptr_t)img & 3) || ((uintptr_t)workspace24 & 3)) {
+        wt::set_error("wd_autocontrast_u8: (H, W, 3) uint8 image, 4-byte aligned, and a 24-byte device workspace");
+        return WT_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    static const unsigned init[6] = {255u, 255u, 255u, 0u, 0u, 0u};
+    WT_HIP(hipMemcpyAsync(workspace24, init, sizeof(init), hipMemcpyHostToDevice, st));
+    const long n_pix = (long)h * w;
+    long blocks = (n_pix / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(autocontrast_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, n_pix, (unsigned*)workspace24);
+    hipLaunchKernelGGL(autocontrast_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, n_pix, (const unsigned*)workspace24);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
 extern "C" int wd_preprocess_f32(const void* src, int src_layout, int batch, int h, int w, double scale, int hflip, int vflip,
                                  int swap_rb, const float* mean3, const float* std3, int divisor, float* out, void* stream_) {
     WT_TRY(wt::ensure_device());

@@ -132,6 +132,9 @@ def autocontrast_(img_u8):
     1069-1075) on a (H, W, 3) uint8 DEVICE tensor: per channel lo / hi = darkest / brightest value present; if hi <= lo the
     channel is unchanged, else lut[v] = clamp(int(v * 255 / (hi - lo) - lo * 255 / (hi - lo)), 0, 255).  Bit-exact with PIL
     (tests/test_gpu_detector.py); float64 like PIL's Python arithmetic."""
+    if img_u8.is_cuda and img_u8.dim() == 3 and img_u8.shape[2] == 3:
+        from .nn import ops
+        return ops.autocontrast_(img_u8.contiguous().clone())          # two HIP launches; the torch formulation below is the CPU-tensor twin
     flat = img_u8.reshape(-1, img_u8.shape[-1])
     lo = flat.amin(0).double()
     hi = flat.amax(0).double()

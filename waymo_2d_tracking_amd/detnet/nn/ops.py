@@ -441,6 +441,16 @@ def preprocess(x, scale=1.0, hflip=False, vflip=False, swap_rb=True, mean=None, 
 
 # ---------------------------------------------------------------------------------------------------------------
 # image decode
+def autocontrast_(img_u8):
+    """PIL's ImageOps.autocontrast (cutoff 0) on an (H, W, 3) uint8 GPU image, IN PLACE, two HIP launches (csrc/det_preprocess.hip:
+    wd_autocontrast_u8), bit-exact with PIL.  Returns the image."""
+    assert img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous()
+    ws = torch.empty(6, dtype=torch.int32, device=img_u8.device)
+    _lib.check(_lib.lib().wd_autocontrast_u8(_p(img_u8), C.c_int(img_u8.shape[0]), C.c_int(img_u8.shape[1]), _p(ws), _stream()),
+               'wd_autocontrast_u8')
+    return img_u8
+
+
 def jpeg_info(data):
     """(width, height, components, h_samp, v_samp, restart_interval) of a baseline JPEG (host-only header parse)."""
     buf = bytes(data)
