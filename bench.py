@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--inflight', type=int, default=1,
                     help='e2e/detect: frames in flight (hipGraph lanes on separate streams); EXPERIMENT: 2 deadlocks at 1920x1280 (spin-waiting library kernels)')
+    ap.add_argument('--auto-contrast', action='store_true', help='e2e/detect: ImageOps.autocontrast on every frame (the --auto-contrast=1 of the '
+                    "reference's documented TTA run, README.md:37)")
     ap.add_argument('--from-jpeg', action='store_true', help='e2e/detect: the frames enter as JPEG bytes and are decoded on the GPU inside the step '
                     '(loader threads, one step ahead); the default keeps decoded frames resident in HBM as the bench contract asks')
     ap.add_argument('--no-defer-track', action='store_true', help='e2e: start the SORT call of a chunk right behind its last frame instead of '

@@ -41,7 +41,7 @@ def moving_frames(n_cameras, n_times, height, width, seed, device):
 class DetectTrackPipeline(object):
     def __init__(self, n_cameras=5, frames_per_camera=2, height=1280, width=1920, seed=0, device='cuda',
                  iou_threshold=(0.01, 0.01, 1.0, 0.0), score_threshold=(0.0, 0.0, 0.0, 0.0), max_age=2, min_hits=0, tta='',
-                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True, n_inflight=1, deterministic=False, defer_tracking=False):
+                 segment_frames=SEGMENT_FRAMES, distinct_times=16, model=None, use_graph=True, n_inflight=1, deterministic=False, defer_tracking=False, auto_contrast=False):
         self.dev = torch.device(device)
         # --tta x1.5,hflip (nn/tta.py:228-267): one pass on the enlarged, flipped image, folded into the pre-processing kernel
         self.tta_scale, self.tta_hflip = 1.0, False
@@ -105,6 +105,7 @@ class DetectTrackPipeline(object):
         self.time = 0                  # frame time index into self.frames
         self.jpeg = None               # enable_jpeg_input(): frames enter as JPEG bytes
         self.defer_tracking = bool(defer_tracking)
+        self.auto_contrast = bool(auto_contrast)      # --auto-contrast=1 of the documented run (README.md:37): ImageOps.autocontrast per frame
         self._pending_track = None
         self.segments_done = 0
 
@@ -116,6 +117,8 @@ class DetectTrackPipeline(object):
     def _detect_core(self, img):
         """uint8 (1, H, W, 3) frame -> wire-format detections in 100 static slots: (xywhs (5, 100) float64, category (100) int32
         with 0 = empty slot).  Static shapes, no host synchronisation: capturable as ONE hipGraph."""
+        if self.auto_contrast:
+            img = ops.autocontrast_(img[0].clone()).unsqueeze(0)
         boxes, scores, classes, cnt = self.model.predict_padded(img, self.tta_scale, self.tta_hflip)
         ho, wo = self.model.last_input_size
         # HFlipTTA.post_process + Detectron2Det.predict + load_prediction in one launch; unused slots: category 0 = ignored
@@ -151,7 +154,8 @@ class DetectTrackPipeline(object):
                 # SORT kernel of the previous chunk (see step()); the second graph reads the first one's output tensors in place
                 lane['graph'] = torch.cuda.CUDAGraph()
                 with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream'], capture_error_mode='thread_local'):
-                    lane['feats'] = self.model.predict_padded_bottom_up(lane['gin'], self.tta_scale, self.tta_hflip)
+                    gin = ops.autocontrast_(lane['gin'][0].clone()).unsqueeze(0) if self.auto_contrast else lane['gin']
+                    lane['feats'] = self.model.predict_padded_bottom_up(gin, self.tta_scale, self.tta_hflip)
                 lane['graph_b'] = torch.cuda.CUDAGraph()
                 with torch.no_grad(), torch.cuda.graph(lane['graph_b'], stream=lane['stream'], pool=lane['graph'].pool(),
                                                        capture_error_mode='thread_local'):
@@ -497,7 +501,7 @@ def run(args, world, rank, timed_steps):
     fps = max(1, args.frames_per_step // 5)
     track = args.stage == 'e2e'
     pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False), n_inflight=getattr(args, 'inflight', 1),
-                               defer_tracking=track and not getattr(args, 'no_defer_track', False))
+                               defer_tracking=track and not getattr(args, 'no_defer_track', False), auto_contrast=getattr(args, 'auto_contrast', False))
     steps = args.steps or 3
     warmup = args.warmup if args.warmup is not None else 1
     state = {'n': 0}
@@ -557,7 +561,7 @@ def run(args, world, rank, timed_steps):
     res = dict(value=frames * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, dtype='f32',
                workload='Cascade R-CNN X152-32x8d-FPN dconv (random-init, fp32, batch 1%s) on synthetic 1920x1280x3 frames'
                         ' -> top-100 detections/frame -> %s; %d cameras x %d frames per step per GPU'
-                        % (', --tta ' + args.tta if getattr(args, 'tta', '') else '',
+                        % ((', --tta ' + args.tta if getattr(args, 'tta', '') else '') + (', --auto-contrast' if getattr(args, 'auto_contrast', False) else ''),
                            'SORT (max_age 2, min_hits 0, all boxes tracked; trackers resident for the whole segment)' if track else 'no tracking', 5, fps),
                roofline=roofline,
                extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_total / max(1, frames * state['n']), hip_graph=pipe._graph is not None, track_rows=n_out, births=births))

@@ -140,13 +140,20 @@ __global__ __launch_bounds__(256) void autocontrast_minmax_kernel(const uint8_t*
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (long p = n4 * 4; p < n_pix; ++p)
             for (int c = 0; c < 3; ++c) { lo[c] = min(lo[c], (unsigned)img[3 * p + c]); hi[c] = max(hi[c], (unsigned)img[3 * p + c]); }
+    __shared__ unsigned red[4][6];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         for (int off = 32; off > 0; off >>= 1) {
             lo[c] = min(lo[c], (unsigned)__shfl_xor((int)lo[c], off));
             hi[c] = max(hi[c], (unsigned)__shfl_xor((int)hi[c], off));
         }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&mm[c], lo[c]); atomicMax(&mm[3 + c], hi[c]); }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][c] = lo[c]; red[threadIdx.x >> 6][3 + c] = hi[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {                                      // six atomics per workgroup (a few hundred per address and image)
+        unsigned v = red[0][threadIdx.x];
+        for (int k = 1; k < 4; ++k) v = threadIdx.x < 3 ? min(v, red[k][threadIdx.x]) : max(v, red[k][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], v); else atomicMax(&mm[threadIdx.x], v);
     }
 }
 
@@ -187,12 +194,13 @@ extern "C" int wd_autocontrast_u8(uint8_t* img, int h, int w, void* workspace24,
         return WT_ERR_INVALID;
     }
     hipStream_t st = (hipStream_t)stream;
-    static const unsigned init[6] = {255u, 255u, 255u, 0u, 0u, 0u};
-    WT_HIP(hipMemcpyAsync(workspace24, init, sizeof(init), hipMemcpyHostToDevice, st));
+    WT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(workspace24), 255, 3, st));                    // min of the channels
+    WT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(static_cast<char*>(workspace24) + 12), 0, 3, st));   // max (memset nodes: capturable)
     const long n_pix = (long)h * w;
     long blocks = (n_pix / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(autocontrast_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, n_pix, (unsigned*)workspace24);
+    hipLaunchKernelGGL(autocontrast_minmax_kernel, dim3((unsigned)(blocks > 512 ? 512 : blocks)), dim3(256), 0, st, img, n_pix,
+                       (unsigned*)workspace24);
     hipLaunchKernelGGL(autocontrast_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, n_pix, (const unsigned*)workspace24);
     WT_HIP(hipGetLastError());
     return WT_OK;
