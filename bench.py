@@ -87,7 +87,7 @@ def init_dist(args):
         import torch.distributed as dist
         if 'RANK' not in os.environ:                 # WT_FORCE_DIST=1 without a launcher: a one-rank group on this GPU
             from waymo_2d_tracking_amd import launcher
-            os.environ.update(launcher.rank_environments(1, launcher.free_port(), {})[0])
+            launcher.adopt_single_rank_env()
         if torch.cuda.device_count() <= local:
             raise SystemExit('bench.py: rank %d needs GPU %d but only %d visible' % (rank, local, torch.cuda.device_count()))
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -131,6 +131,9 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
+PER_RANK_MS = []          # ms per step as each rank measured it (last timed_steps call; empty without a process group)
+
+
 def timed_steps(world, run_step, steps, warmup):
     """W untimed + exactly K timed steps bracketed by barrier + synchronize; max over ranks; also HIP events."""
     import torch
@@ -147,11 +150,14 @@ def timed_steps(world, run_step, steps, warmup):
     barrier_sync(world)
     dt = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
+    PER_RANK_MS.clear()
     if _dist_on():
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = torch.zeros(dist.get_world_size(), dtype=torch.float64, device='cuda')
+        dist.all_gather_into_tensor(every, t)          # every rank's own wall time between the two barriers
+        PER_RANK_MS.extend(1e3 * x / steps for x in every.cpu().tolist())
+        dt = float(every.max().item())                 # the job's time = the slowest rank's
     return dt, ev_ms
 
 
@@ -519,9 +525,15 @@ def main():
     if _dist_on():
         import torch.distributed as dist
         dist.barrier()
+    if ranks_seen is not None and (len(ranks_seen) != args.gpus or sorted(ranks_seen) != list(range(args.gpus))) \
+            and os.environ.get('WT_FORCE_DIST') != '1':
+        # the line below would carry a throughput for a job that is not the one asked for: no line, non-zero exit
+        raise SystemExit('bench.py: --gpus %d but RCCL connected ranks %s' % (args.gpus, ranks_seen))
     if rank == 0:
         if ranks_seen is not None:
             res.setdefault('extra', {})['rccl_ranks'] = ranks_seen
+            if PER_RANK_MS:
+                res['extra']['per_rank_ms_per_step'] = dict(min=min(PER_RANK_MS), max=max(PER_RANK_MS), by_rank=list(PER_RANK_MS))
         line = {'metric': metric, 'value': res['value'], 'unit': res['unit'], 'n_gpus': world, 'steps': steps,
                 'warmup': warmup, 'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': res['dtype'], 'data': 'synthetic',

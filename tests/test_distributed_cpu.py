@@ -191,6 +191,26 @@ def test_launcher_environment_and_refusal(tmp_path):
     assert [e['RANK'] for e in envs] == ['0', '1', '2', '3'] and [e['LOCAL_RANK'] for e in envs] == ['0', '1', '2', '3']
     assert all(e['WORLD_SIZE'] == '4' and e['MASTER_ADDR'] == '127.0.0.1' and e['MASTER_PORT'] == '23456' for e in envs)
     assert all(e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and e['PATH'] == '/usr/bin' for e in envs)
+    # N > 1: every rank gets its own MIOpen user database / cache and TunableOp result file (8 ranks in find mode on a fresh box
+    # must not write one sqlite file); a location the user exported wins; one rank keeps the library defaults
+    dirs = [(e['MIOPEN_USER_DB_PATH'], e['MIOPEN_CUSTOM_CACHE_DIR'], e['WT_TUNABLEOP_OUT']) for e in
+            L.rank_environments(4, 23456, base_env={}, scratch=str(tmp_path / 'cache'))]
+    assert len({d[0] for d in dirs}) == 4 and len({d[2] for d in dirs}) == 4 and all(os.path.isdir(d[0]) and os.path.isdir(d[1]) for d in dirs)
+    kept = L.rank_environments(2, 23456, base_env={'MIOPEN_USER_DB_PATH': '/x', 'OMP_NUM_THREADS': '3'}, scratch=str(tmp_path / 'cache'))
+    assert all(e['MIOPEN_USER_DB_PATH'] == '/x' and e['OMP_NUM_THREADS'] == '3' for e in kept)
+    assert 'MIOPEN_USER_DB_PATH' not in L.rank_environments(1, 23456, base_env={})[0]
+    # WT_FORCE_DIST=1 without a launcher: only the rendezvous variables are adopted, a user's thread count survives
+    saved = dict(os.environ)
+    try:
+        os.environ['OMP_NUM_THREADS'] = '5'
+        for k in L.RENDEZVOUS_KEYS:
+            os.environ.pop(k, None)
+        L.adopt_single_rank_env(port=23999)
+        assert os.environ['OMP_NUM_THREADS'] == '5' and os.environ['RANK'] == '0' and os.environ['WORLD_SIZE'] == '1'
+        assert os.environ['MASTER_PORT'] == '23999' and os.environ['MASTER_ADDR'] == '127.0.0.1'
+    finally:
+        os.environ.clear()
+        os.environ.update(saved)
     import pytest
     with pytest.raises(L.LaunchError, match='only 1 GPU'):
         L.spawn_local_ranks([sys.executable, '-c', 'pass'], 2, n_devices=1)      # never oversubscribe a GPU

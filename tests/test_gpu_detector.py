@@ -341,11 +341,12 @@ def test_training_step_through_ddp_over_rccl(tmp_path):
     import json
     import subprocess
     import sys
+    from waymo_2d_tracking_amd.launcher import free_port
     code = r'''
 import json, os, sys
 sys.path.insert(0, %r)
 import torch, torch.nn as nn, torch.distributed as dist
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29633', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(%d), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
 from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
@@ -371,7 +372,7 @@ worst = max(float((p.grad - g0[n]).abs().max() / (g0[n].abs().max() + 1e-30)) fo
 rep = dict(l0=float(l0), l1=float(l1), worst=worst, n=len(g0), missing=[n for n, p in m.model.named_parameters() if p.requires_grad and p.grad is None])
 dist.barrier(); dist.destroy_process_group()
 json.dump(rep, open(%r, 'wt'))
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / 'rep.json'))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), free_port(), str(tmp_path / 'rep.json'))
     p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True,
                        text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]

@@ -334,11 +334,12 @@ def test_per_chunk_exchange_over_rccl_single_rank(tmp_path):
     import json
     import subprocess
     import sys
+    from waymo_2d_tracking_amd.launcher import free_port
     code = r'''
 import json, os, sys
 sys.path.insert(0, %r)
 import torch, torch.distributed as dist
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29611', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(%d), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
 from waymo_2d_tracking_amd.bench_e2e import DetectTrackPipeline, check_against, collation_report
@@ -353,7 +354,7 @@ rep = collation_report(pipe, 1, 0)
 rep['oracle'] = check_against(pipe, O.track_streams)
 dist.barrier(); dist.destroy_process_group()
 json.dump(rep, open(%r, 'wt'))
-''' % (ROOT, str(tmp_path / 'rep.json'))
+''' % (ROOT, free_port(), str(tmp_path / 'rep.json'))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -361,3 +362,28 @@ json.dump(rep, open(%r, 'wt'))
     assert rep['rccl_ranks'] == [0] and rep['backend'] == 'nccl' and rep['exchanges'] == 3
     assert rep['collated_ok'] and rep['collated_chunks'] == 3 and rep['collated_rows_by_rank'][0] == rep['oracle']['rows'] > 0
     assert rep['births_by_rank'][0] == rep['oracle']['births'] and rep['oracle']['ok']
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(tmp_path):
+    """The first multi-rank run should not be the driver's: `bench.py --gpus 2` through the package's own launcher when the box has
+    two GPUs (skipped on the 1-GPU boxes of the pool).  n_gpus is what RCCL connected, the collated block of rank 0 equals its own
+    rows, ids of rank 1 start behind the births of rank 0 (reference: the process-global counter, tracking/sort/sort.py:86), and the
+    per-rank step times are reported."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two visible GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    ex = line['extra']
+    assert line['n_gpus'] == 2 and ex['rccl_ranks'] == [0, 1] and ex['collated_ok']
+    assert ex['id_offsets'][0] == 0 and ex['id_offsets'][1] == ex['births_by_rank'][0] > 0
+    assert len(ex['per_rank_ms_per_step']['by_rank']) == 2 and ex['per_rank_ms_per_step']['max'] <= line['ms_per_step'] * 1.001
+    assert line['verified']['ok']

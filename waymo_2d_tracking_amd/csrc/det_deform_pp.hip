@@ -660,8 +660,8 @@ static int scratch_table(size_t bytes, hipStream_t stream, void** out) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &st);
         if (st != hipStreamCaptureStatusNone) {
-            wt::set_error("wd_deform_conv3x3: the sampling-table scratch must grow inside a stream capture; run the shape once eagerly on "
-                          "this stream or pass a table (wd_deform_offsets_table_f32)");
+            wt::set_error("wd_deform_conv3x3: the sampling-table scratch would have to grow, which is not possible inside a stream capture: run "
+                          "the shape once eagerly on this stream first, or pass a table (wd_deform_offsets_table_f32)");
             return WT_ERR_INVALID;
         }
         void* fresh = nullptr;

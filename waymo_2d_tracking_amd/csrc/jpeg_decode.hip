@@ -602,9 +602,17 @@ Ctx* acquire() {
     return c;
 }
 
+// hands the context back; when work has been enqueued on `st` (dirty) the stream is drained first - on an error return queued kernels
+// may still read or write the buffers the next holder of the context is about to memcpy into, grow or free
 struct Release {
     Ctx* c;
-    ~Release() { std::lock_guard<std::mutex> lock(g_mu); c->busy = false; }
+    hipStream_t st = nullptr;
+    bool dirty = false;
+    ~Release() {
+        if (dirty) (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> lock(g_mu);
+        c->busy = false;
+    }
 };
 
 int grow(Ctx& c, size_t blob, size_t work) {
@@ -670,6 +678,10 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
         wt::set_error("wd_jpeg_decode_rgb_u8: output needs %lld bytes, capacity %lld", (long long)hd.width * hd.height * 3, (long long)capacity);
         return WT_ERR_CAPACITY;
     }
+    // every restart marker takes two bytes of the scan: a header that announces more segments than the file can hold is refused
+    // before anything is allocated for it (a few hundred bytes could otherwise reserve gigabytes in the grow-only contexts)
+    if ((size_t)(p.expected_segments - 1) > ((size_t)n - p.scan_pos) / 2)
+        return fail("restart interval / frame size announce more restart segments than the file holds (truncated or corrupt file)");
     const Layout L = jdh::layout_for((size_t)n, p.scan_pos, p.expected_segments);
     size_t planes_bytes = 0;
     for (int c = 0; c < hd.ncomp; ++c) planes_bytes = (size_t)hd.plane_off[c] + wt::align_up((size_t)hd.plane_pitch[c] * hd.plane_rows[c]);
@@ -689,6 +701,7 @@ extern "C" int wd_jpeg_decode_rgb_u8(const uint8_t* data, int64_t n, uint8_t* rg
     memcpy(ctx->host + L.luts, p.luts, sizeof(p.luts));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t used = L.stream + (size_t)hd.nsub * jd::SUB_BYTES + 16;
+    rel.st = st; rel.dirty = true;                     // from here on every return path drains the stream before the context is reused
     WT_HIP(hipMemcpyAsync(ctx->dev, ctx->host, used, hipMemcpyHostToDevice, st));
     WT_HIP(hipMemsetAsync(ctx->work, 0, o_zero_end, st));                                    // counts, bases, flags, candidate counts
     WT_HIP(hipMemsetAsync(ctx->work + o_coef, 0, (size_t)hd.total_blocks * 128, st));        // coefficients

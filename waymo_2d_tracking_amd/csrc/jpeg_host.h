@@ -157,7 +157,8 @@ inline const char* parse(const uint8_t* d, size_t n, Parsed& out) {
         hd.comp_off[c] = hd.bpm;
         hd.comp_nblk[c] = hd.comp_h[c] * hd.comp_v[c];
         for (int j = 0; j < hd.comp_nblk[c]; ++j) {
-            if (hd.bpm >= jd::MAX_BPM) return ("more than 10 blocks per MCU");
+            // launch 0 of the candidate kernel starts one decode per block-in-MCU index with CAND_SLOTS threads per subsequence
+            if (hd.bpm >= jd::MAX_BPM || hd.bpm >= jd::CAND_SLOTS) return ("unsupported: more than 8 blocks per MCU");
             hd.blk_comp[hd.bpm++] = (uint8_t)c;
         }
         hd.plane_off[c] = plane;
@@ -221,6 +222,8 @@ inline const char* unstuff(const uint8_t* d, size_t n, size_t pos, const Layout&
         if (nb == 0) { stream[w++] = 0xFF; pos += 2; continue; }
         if (nb == 0xFF) { pos += 1; continue; }                           // fill byte
         if (nb >= 0xD0 && nb <= 0xD7) {
+            // a restart segment without a single byte (two markers in a row): its blocks would stay zero unnoticed
+            if (w == (size_t)seg_first[seg] * SB) return ("empty restart segment (truncated or corrupt file)");
             seg_end[seg] = (uint32_t)(w * 8);
             const size_t padded = (w + SB - 1) / SB * SB;
             memset(stream + w, 0xFF, padded - w);
@@ -233,6 +236,7 @@ inline const char* unstuff(const uint8_t* d, size_t n, size_t pos, const Layout&
         }
         end = true;                                                         // EOI or any other marker ends the scan
     }
+    if (seg > 0 && w == (size_t)seg_first[seg] * SB) return ("empty restart segment (truncated or corrupt file)");
     seg_end[seg] = (uint32_t)(w * 8);
     const size_t padded = (w + SB - 1) / SB * SB;
     memset(stream + w, 0xFF, padded - w + 16);

@@ -164,8 +164,6 @@ def resize_size(w, h, size, max_size=None):
 
 
 class ImageLoader(object):
-    _warned = False
-
     """Decode ahead of the detector in a thread pool.  JPEG files: the file bytes go to the GPU and are decoded there
     (ops.jpeg_decode: Huffman, IDCT, upsampling, colour conversion in HIP kernels; bit-exact with PIL's decode, ~1 MB
     instead of 7.4 MB over PCIe per 1920x1280 frame).  With --resize, or for other formats: PIL decode + ToRGB (+ Resize,
@@ -177,6 +175,8 @@ class ImageLoader(object):
     Transform order of the reference (detnet/inference.py:170-178): ToRGB, AutoContrast, [CLAHE], Resize.  Without --resize
     AutoContrast runs on the GPU (autocontrast_, bit-exact with PIL); with --resize it has to precede the resize, so the
     loader thread applies PIL's own ImageOps.autocontrast before resizing (`auto_contrast_in_loader`)."""
+    _warned = False                 # the PIL hand-over of an unsupported JPEG flavour is announced once
+
 
     def __init__(self, items, resize=None, max_image_size=None, workers=4, depth=4, auto_contrast=False, decoder='gpu'):
         self.items, self.resize, self.max_size = items, resize, max_image_size

@@ -2,7 +2,8 @@
 (/root/reference/detnet/trainer/test.py:227-255: one spawned process per dataset split, `cuda_device_id = i % n_gpu`;
 detnet/trainer/launch.sh:3-9 for the training side).
 
-`spawn_local_ranks` is used by `bench.py --gpus N` (and by the CLIs' `-j N`) when no launcher set WORLD_SIZE: the parent
+`spawn_local_ranks` is used by `bench.py --gpus N` when no launcher set WORLD_SIZE (the CLIs run under `torchrun`; their
+`-j N` is the number of loader threads per rank, like the reference's `--jobs`): the parent
 must not have touched the GPU (no HIP call, no `torch.cuda.is_available()`): it only counts devices (which does not
 initialise the runtime on this image), starts N fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
 MASTER_PORT in their environment, forwards their output, and fails if any child fails.  Children are plain
@@ -33,9 +34,23 @@ def visible_gpus():
     return int(torch.cuda.device_count())
 
 
-def rank_environments(n_ranks, port, base_env=None):
+RENDEZVOUS_KEYS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')
+
+
+def per_rank_cache_env(rank, n_ranks, scratch=None):
+    """Library caches that N ranks of one node must not share on a fresh box: every rank runs MIOpen's find mode for the same
+    convolutions during warm-up and would write the same user database (sqlite, one writer), and TunableOp's result file is
+    written at exit.  One directory / file per rank, under `scratch` (default: the system temp directory)."""
+    import tempfile
+    root = scratch or os.path.join(tempfile.gettempdir(), 'wt_rank_cache_%d' % os.getuid())
+    d = os.path.join(root, 'rank%d_of_%d' % (rank, n_ranks))
+    return {'MIOPEN_USER_DB_PATH': os.path.join(d, 'miopen'), 'MIOPEN_CUSTOM_CACHE_DIR': os.path.join(d, 'miopen_cache'),
+            'WT_TUNABLEOP_OUT': os.path.join(d, 'tunableop.csv')}
+
+
+def rank_environments(n_ranks, port, base_env=None, scratch=None):
     """The environment of every child: torchrun's variables for a single node, rendezvous on 127.0.0.1 (the
-    container's hostname may not resolve)."""
+    container's hostname may not resolve); values the user already set (thread counts, IPC mode, cache locations) win."""
     base = dict(os.environ if base_env is None else base_env)
     envs = []
     for r in range(n_ranks):
@@ -44,8 +59,25 @@ def rank_environments(n_ranks, port, base_env=None):
                  MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WT_LAUNCHED_BY='waymo_2d_tracking_amd.launcher')
         e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this pool (RCCL needs it)
         e.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n_ranks)))
+        if n_ranks > 1:
+            for k, v in per_rank_cache_env(r, n_ranks, scratch).items():
+                if k not in e:
+                    e[k] = v
+                    if k != 'WT_TUNABLEOP_OUT':
+                        os.makedirs(v, exist_ok=True)
+                    else:
+                        os.makedirs(os.path.dirname(v), exist_ok=True)
         envs.append(e)
     return envs
+
+
+def adopt_single_rank_env(port=None):
+    """WT_FORCE_DIST=1 without a launcher: make this process rank 0 of a one-rank group.  Only the rendezvous variables are written
+    into os.environ - a thread count or IPC mode the user exported stays as it is."""
+    env = rank_environments(1, port or free_port(), {})[0]
+    for k in RENDEZVOUS_KEYS:
+        os.environ[k] = env[k]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 
 def spawn_local_ranks(argv, n_ranks, port=None, n_devices=None, poll_s=0.2, timeout_s=None):
