@@ -483,3 +483,41 @@ def test_autocontrast_kernel_equals_pil_for_every_range_and_on_images():
     img = Image.open(io.BytesIO(buf.getvalue())).convert('RGB')
     got = ops.autocontrast_(torch.from_numpy(np.array(img)).cuda()).cpu().numpy()
     assert np.array_equal(got, np.asarray(ImageOps.autocontrast(img)))
+
+
+def test_roi_pool_workgroup_kernel_equals_row_kernel_and_ignores_the_processing_order(monkeypatch):
+    """Round 4: one workgroup per ROI (weight tables once, sliding 3-bin fold, bucket-ordered processing) against the round-2 kernel
+    (one wave per bin row, dense fold) on the roofline tool's ROI distribution plus tiny / border / degenerate boxes: same sums in a
+    different association -> 1e-5 relative; the processing order changes nothing at all (bit-equal)."""
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    g = torch.Generator().manual_seed(5)
+    strides = [4, 8, 16, 32]
+    H, W, C = 320, 480, 256
+    feats = [_cl(torch.randn((1, C, H // s, W // s), generator=g)) for s in strides]
+    n = 1500
+    size = torch.exp(torch.empty(n).uniform_(0.5, 6.2, generator=g))          # 1.6 .. 490 px: bins far below a pixel up to whole-image boxes
+    ar = torch.exp(torch.empty(n).uniform_(-1.0, 1.0, generator=g))
+    w, h = size * ar.sqrt(), size / ar.sqrt()
+    cx = torch.empty(n).uniform_(-30, W + 30, generator=g)
+    cy = torch.empty(n).uniform_(-30, H + 30, generator=g)
+    rois = torch.stack([torch.zeros(n), cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    rois[7] = torch.tensor([0.0, -50.0, -50.0, 900.0, 700.0])                 # beyond the 64 x 64 tables
+    rois[8] = torch.tensor([0.0, 100.0, 100.0, 100.0, 100.0])                 # empty
+    rois[9] = torch.tensor([3.0, 10.0, 10.0, 50.0, 50.0])                     # bad batch index -> zeros
+    rois = rois.cuda()
+    sc = [1.0 / s for s in strides]
+    monkeypatch.setenv('WD_ROI_KERNEL', 'row')
+    ref = ops.roi_pool_fpn(feats, rois, sc).clone()
+    monkeypatch.setenv('WD_ROI_KERNEL', 'wg')
+    monkeypatch.setenv('WD_ROI_ORDER', '0')
+    plain = ops.roi_pool_fpn(feats, rois, sc).clone()
+    monkeypatch.setenv('WD_ROI_ORDER', '1')
+    ordered = ops.roi_pool_fpn(feats, rois, sc).clone()
+    assert torch.equal(plain, ordered)
+    assert float(plain[9].abs().max()) == 0.0
+    err = (plain - ref).abs().max() / ref.abs().max()
+    assert float(err) <= 1e-5, float(err)
+    # fewer ROIs than the ordering kernel bothers with, and more than one workgroup round
+    for m in (1, 63, 64, 1500):
+        a = ops.roi_pool_fpn(feats, rois[:m].contiguous(), sc)
+        assert torch.equal(a, plain[:m])

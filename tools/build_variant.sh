@@ -1,10 +1,14 @@
 #!/bin/bash
-# build csrc/variants/lib_<name>.so with extra hipcc flags for det_deform_pp.hip (kernel experiments; not shipped)
-# usage: tools/build_variant.sh name "-DFLAG ..."
+# build csrc/variants/lib_<name>.so with extra hipcc flags for ONE unit (kernel experiments; not shipped); load it with WT_LIB_PATH
+# usage: tools/build_variant.sh name "-DFLAG ..." [unit.hip, default det_deform_pp.hip]
 set -e
 cd "$(dirname "$0")/../waymo_2d_tracking_amd/csrc"
 mkdir -p variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math $2 -c det_deform_pp.hip -o variants/pp_$1.o
-objs=$(ls *.o | grep -v det_deform_pp.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/lib_$1.so $objs variants/pp_$1.o
+unit=${3:-det_deform_pp.hip}
+base=${unit%.hip}
+extra=""
+case $unit in det_deform_pp.hip) extra="-fno-slp-vectorize";; det_gemm.hip|det_backward.hip) extra="-munsafe-fp-atomics";; sort_*|ensemble.hip|det_tail.hip|det_preprocess.hip) extra="-ffp-contract=off";; esac
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math $extra $2 -c $unit -o variants/${base}_$1.o
+objs=$(ls *.o | grep -v "^${base}.o$")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/lib_$1.so $objs variants/${base}_$1.o
 echo variants/lib_$1.so

@@ -64,7 +64,7 @@ for li, s in enumerate(strides):
         summed_px += max(x1 - x0, 0) * max(y1 - y0, 0)
     unique_px += int(m.sum())
 alg = unique_px * 256 * 4 + n * 20 + n * 49 * 256 * 4
-out['roi_pool_row_kernel'] = dict(us=us, algorithmic_bytes=alg, unique_footprint_bytes=unique_px * 256 * 4,
+out['roi_pool_wg_kernel'] = dict(us=us, algorithmic_bytes=alg, unique_footprint_bytes=unique_px * 256 * 4,
                                   per_roi_footprint_sum_bytes=summed_px * 256 * 4, output_bytes=n * 49 * 256 * 4,
                                   gbs=alg / us / 1e3, frac_of_8TBs=alg / us / 1e3 / 8000)
 del pyramids

@@ -16,7 +16,7 @@ def load(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         n = r['Kernel_Name']
-        for key in ('roi_pool_row_kernel', 'roi_pool_sep_kernel', 'nms_mask_kernel', 'nms_sweep_col_kernel', 'preprocess_kernel'):
+        for key in ('roi_pool_wg_kernel', 'roi_bucket_order_kernel', 'roi_pool_row_kernel', 'roi_pool_sep_kernel', 'nms_mask_kernel', 'nms_sweep_col_kernel', 'preprocess_kernel'):
             if key in n:
                 acc[key + ' grid=' + r.get('Grid_Size', '?')][r['Counter_Name']].append(float(r['Counter_Value']))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} | {'launches': len(next(iter(d.values())))} for k, d in acc.items()}
