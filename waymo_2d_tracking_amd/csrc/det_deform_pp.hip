@@ -58,8 +58,9 @@ constexpr unsigned FAR_Y = 0xFFFFFFFFu;    // entry.y of a sample whose corners 
 #endif
 constexpr int RW = PP_RES_TAPS;
 template <int CG> constexpr int tap_floats() { return (CG == 32 ? 4 : 2) * 64 * 4; }     // weights of one tap of an item
-template <int CG> constexpr size_t smem_bytes() {
-    return (size_t)(9 - RW) * tap_floats<CG>() * 4 + 4 * (size_t)PATCH_B + 4 * (size_t)TAB_B;
+constexpr int PS_WIDE = 21;            // stride 2: 17 x 17 footprint of the undeformed taps of an 8 x 8 output tile + the same 2-pixel halo
+template <int CG, int PSIDE = PS, int NT = 2> constexpr size_t smem_bytes() {
+    return (size_t)(9 - RW) * tap_floats<CG>() * 4 + 2 * NT * (size_t)((PSIDE * PSIDE + 1) * CH * 4) + 2 * NT * (size_t)TAB_B;
 }
 }  // namespace pp
 
@@ -102,15 +103,17 @@ __device__ __forceinline__ int pp_slot(int p, int q) { return (p << 3) + (q ^ ((
 // Stride S (1 or 2): the patch origin is image pixel (S * 8 ty - org, S * 8 tx - org) with org = 3 for stride 1 (2-pixel halo around the
 // 10 x 10 footprint of undeformed taps) and org = -1 for stride 2: there the undeformed footprint is 17 x 17, the 14 x 14 patch holds its
 // middle rows / columns 1 .. 14 and the rest (about a third of the samples) takes the far path - still 2 - 3 x faster than the gather kernel.
-__device__ __forceinline__ int pp_origin(int stride) { return stride == 1 ? 3 : -1; }
+// round 4: stride 2 gets its own instantiation with 21 x 21 patches (one team, one wave per SIMD: the patches take the LDS of the second team):
+// origin 3 like stride 1, no sample of an undeformed tap leaves the patch.
+__device__ __forceinline__ int pp_origin(int stride, int ps) { return (stride == 1 || ps == pp::PS_WIDE) ? 3 : -1; }
 
 __device__ __forceinline__ uint4 pp_make_entry(bool pixel_in_image, int yy, int xx, int kh, int kw, float2 ov, int ty, int tx, int H, int W,
-                                               int stride) {
-    const int org = pp_origin(stride);
+                                               int stride, int ps) {
+    const int org = pp_origin(stride, ps);
     const float t_fy = (float)(stride * yy + kh - 1 + org), t_fx = (float)(stride * xx + kw - 1 + org);   // undeformed sample, patch coordinates
     const float py0 = (float)(ty * 8 * stride - org), px0 = (float)(tx * 8 * stride - org);
     const float fH = (float)H, fW = (float)W;
-    unsigned s0 = pp_slot(pp::NPIX, 0), s1 = s0, s2 = s0, s3 = s0;        // the zero pixel: contributes nothing
+    unsigned s0 = pp_slot(ps * ps, 0), s1 = s0, s2 = s0, s3 = s0;         // the zero pixel: contributes nothing
     float lh = 0.f, lw = 0.f;
     uint4 e;
     if (pixel_in_image) {
@@ -120,9 +123,9 @@ __device__ __forceinline__ uint4 pp_make_entry(bool pixel_in_image, int yy, int 
             const float fy = floorf(ry), fx = floorf(rx);
             const int hl = (int)fy, wl = (int)fx;
             lh = ry - fy; lw = rx - fx;
-            if ((unsigned)hl <= (unsigned)(pp::PS - 2) && (unsigned)wl <= (unsigned)(pp::PS - 2)) {
-                const int u = hl * pp::PS + wl;
-                s0 = pp_slot(u, 0); s1 = pp_slot(u + 1, 0); s2 = pp_slot(u + pp::PS, 0); s3 = pp_slot(u + pp::PS + 1, 0);
+            if ((unsigned)hl <= (unsigned)(ps - 2) && (unsigned)wl <= (unsigned)(ps - 2)) {
+                const int u = hl * ps + wl;
+                s0 = pp_slot(u, 0); s1 = pp_slot(u + 1, 0); s2 = pp_slot(u + ps, 0); s3 = pp_slot(u + ps + 1, 0);
             } else {
                 const int ih = hl + ty * 8 * stride - org, iw = wl + tx * 8 * stride - org;     // |.| < 2^15: feature maps are a few thousand pixels at most
                 e.x = (unsigned)(ih + 32768) | ((unsigned)(iw + 32768) << 16);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(576) void deform_offsets_table_kernel(const float* 
             ov = make_float2(a0, a1);
             *reinterpret_cast<float2*>(offsets + (((size_t)tn * H + oy) * W + ox) * 18 + 2 * k) = ov;
         }
-        const uint4 ent = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, H, W, 1);
+        const uint4 ent = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, H, W, 1, pp::PS);
         table[(size_t)t * pp::NE + e] = ent;
         pp_tile_flag(ent.y == pp::FAR_Y, t, ntiles, table);
     }
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(576) void deform_offsets_table_kernel(const float* 
 // The same table from an offsets tensor (N, H, W, 18) that already exists (callers without the fused pre-pass).
 // H, W: the OUTPUT grid (tiles, offsets); Hin, Win: the sampled image (== H, W at stride 1).
 __global__ __launch_bounds__(576) void deform_table_kernel(const float* __restrict__ offsets, int batch, int Hin, int Win, int H, int W,
-                                                          int stride, uint4* __restrict__ table) {
+                                                          int stride, int ps, uint4* __restrict__ table) {
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const int ntiles = batch * tiles_y * tiles_x;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(576) void deform_table_kernel(const float* __restri
         const bool in = oy < H && ox < W;
         float2 ov = make_float2(0.f, 0.f);
         if (in) ov = *reinterpret_cast<const float2*>(offsets + (((size_t)tn * H + oy) * W + ox) * 18 + 2 * k);
-        const uint4 ent = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, Hin, Win, stride);
+        const uint4 ent = pp_make_entry(in, yy, xx, kh, kw, ov, ty, tx, Hin, Win, stride, ps);
         table[(size_t)t * pp::NE + e] = ent;
         pp_tile_flag(ent.y == pp::FAR_Y, t, ntiles, table);
     }
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(576) void deform_table_kernel(const float* __restri
 // BF3 (exploratory, 32 channels per group only): the implicit GEMM as three bf16 MFMAs per 16-channel tile and tap (hi.hi + hi.lo + lo.hi of a
 // 2-way bfloat16 split of weights and samples, f32 accumulation) on the bf16 matrix pipe - 6 x ~17 cycles instead of 16 x 32, and that pipe
 // overlaps with VALU.  About 16 mantissa bits per operand: NOT fp32; measured and reported as an `extra` only (tools/bf16x3_experiment.py).
-template <int CG, bool BF3 = false>
-__global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
+template <int CG, bool BF3 = false, int PSIDE = pp::PS, int NT = 2>
+__global__ __launch_bounds__(256 * NT, NT) __attribute__((amdgpu_waves_per_eu(NT, NT))) void deform_conv3x3_pp_kernel(
     const float* __restrict__ x, const float* __restrict__ wfrag, const float* __restrict__ scale, const float* __restrict__ bias,
     int relu, int batch, int H, int W, int Ho, int Wo, int stride, int C, int Cout, int nsplit, float* __restrict__ y,
     const uint4* __restrict__ table) {
@@ -224,24 +227,28 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     static_assert(!BF3 || CG == 32, "the bf16x3 experiment exists for 32 channels per group only");
     constexpr int NQ = CG == 32 ? 4 : 2;                     // float4 weight fragments per lane and tap
     constexpr int RW = pp::RW;
+    constexpr int PS = PSIDE, NPIX = PS * PS;                // patch side / pixels (+ pixel NPIX = zeros)
+    constexpr int PATCH_F = (NPIX + 1) * pp::CH, PATCH_B = PATCH_F * 4;
+    constexpr int NPC = (NPIX * 8 + 255) / 256;              // LDS-DMA pieces (64 slots of 16 bytes) per wave and patch
+    static_assert((NPIX + 1) * 8 * 16 <= 65536, "corner byte offsets are 16 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bw = reinterpret_cast<float*>(smem);                                            // taps RW..8
     constexpr unsigned PATCH0 = (unsigned)((9 - RW) * pp::tap_floats<CG>() * 4);           // LDS byte offset of the patch buffers
-    constexpr unsigned TAB0 = PATCH0 + 4u * pp::PATCH_B;                                   // ... of the table buffers
+    constexpr unsigned TAB0 = PATCH0 + 2u * NT * PATCH_B;                                   // ... of the table buffers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: scalar branches on team / slot
     const int team = wave >> 2, m = wave & 3;
     const int r16 = lane & 15, kq = lane >> 4;
     const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
     const int ntiles = batch * tiles_y * tiles_x;
-    const int org = pp_origin(stride), tstep = 8 * stride;                                 // patch origin = tile * tstep - org
+    const int org = pp_origin(stride, PS), tstep = 8 * stride;                                 // patch origin = tile * tstep - org
     const int g = blockIdx.x / nsplit, sidx = blockIdx.x - g * nsplit;                     // g = item (32 channels)
     // contiguous tile range of this workgroup
     const int tq = ntiles / nsplit, trm = ntiles - tq * nsplit;
     const int t0 = sidx * tq + (sidx < trm ? sidx : trm);
     const int t1 = t0 + tq + (sidx < trm ? 1 : 0);
-    const int n_items = (t1 - t0 + 1) >> 1;                 // per team (the last one of team 1 may be a dummy)
-    const unsigned patch_b0 = PATCH0 + (unsigned)team * 2u * pp::PATCH_B;                  // this team's patch buffer 0
+    const int n_items = (t1 - t0 + NT - 1) / NT;             // per team (the last one of team 1 may be a dummy)
+    const unsigned patch_b0 = PATCH0 + (unsigned)team * 2u * PATCH_B;                  // this team's patch buffer 0
     const unsigned tab_b0 = TAB0 + (unsigned)team * 2u * pp::TAB_B;                        // ... table buffer 0
     const int c0 = g * pp::CH;
     const long HW = (long)H * W, HWo = (long)Ho * Wo;
@@ -251,14 +258,14 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     // The patch goes global -> LDS without passing through registers (global_load_lds: the LDS image of one wave
     // instruction is lane-linear, 64 x 16 bytes; the XOR swizzle is applied on the SOURCE side).  Wave m of a team issues
     // instructions j = 0..6 covering LDS slots (7 m + j) * 64 + lane.
-    int p_rel[7], p_rc[7];                  // byte offset from the patch origin pixel, (row << 8 | col) or 0xFFFF
+    int p_rel[NPC], p_rc[NPC];                  // byte offset from the patch origin pixel, (row << 8 | col) or 0xFFFF
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int sl = (7 * m + j) * 64 + lane;
+    for (int j = 0; j < NPC; ++j) {
+        const int sl = (NPC * m + j) * 64 + lane;
         const int pxl = sl >> 3, q = (sl & 7) ^ ((pxl >> 1) & 7);
-        const int r = pxl / pp::PS, cc = pxl - r * pp::PS;
+        const int r = pxl / PS, cc = pxl - r * PS;
         p_rel[j] = ((r * W + cc) * C + q * 4) * 4;
-        p_rc[j] = (sl < pp::NPIX * 8) ? ((r << 8) | cc) : 0xFFFF;
+        p_rc[j] = (sl < NPIX * 8) ? ((r << 8) | cc) : 0xFFFF;
     }
 
     struct TileXY { int tn, ty, tx; };
@@ -275,11 +282,11 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
         return r;
     };
     auto tile_xy = [&](int it) {
-        int t = t0 + team + 2 * it;
+        int t = t0 + team + NT * it;
         t = t < t1 ? t : t1 - 1;
         return tile_of(t);
     };
-    auto tile_valid = [&](int it) { return t0 + team + 2 * it < t1; };
+    auto tile_valid = [&](int it) { return t0 + team + NT * it < t1; };
 
     // one LDS-DMA instruction: 64 lanes x 16 bytes from (sbase + voff) to LDS byte offset `dst` + 16 * lane.  Inline asm, not
     // __builtin_amdgcn_global_load_lds: hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every LDS-DMA that follows another
@@ -292,22 +299,22 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     auto issue_patch = [&](const TileXY& T, unsigned base) {
         const int py0 = T.ty * tstep - org, px0 = T.tx * tstep - org;
         const char* pbase = xb + (((long)T.tn * HW + (long)py0 * W + px0) * C + c0) * 4;
-        const bool inner = py0 >= 0 && px0 >= 0 && py0 + pp::PS <= H && px0 + pp::PS <= W;
+        const bool inner = py0 >= 0 && px0 >= 0 && py0 + PS <= H && px0 + PS <= W;
         if (inner) {
             // interior tile (wave-uniform): scalar base + the per-lane constant offset, no bounds logic
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int s0 = (7 * m + j) * 64;                     // wave-uniform first slot of this instruction
-                if (s0 + 64 <= pp::NPIX * 8) dma16(pbase, p_rel[j], base + s0 * 16);
-                else if (s0 < pp::NPIX * 8) { if (p_rc[j] != 0xFFFF) dma16(pbase, p_rel[j], base + s0 * 16); }
+            for (int j = 0; j < NPC; ++j) {
+                const int s0 = (NPC * m + j) * 64;                     // wave-uniform first slot of this instruction
+                if (s0 + 64 <= NPIX * 8) dma16(pbase, p_rel[j], base + s0 * 16);
+                else if (s0 < NPIX * 8) { if (p_rc[j] != 0xFFFF) dma16(pbase, p_rel[j], base + s0 * 16); }
             }
             return;
         }
         float* pb = reinterpret_cast<float*>(smem + base);
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int s0 = (7 * m + j) * 64;
-            if (s0 >= pp::NPIX * 8) continue;
+        for (int j = 0; j < NPC; ++j) {
+            const int s0 = (NPC * m + j) * 64;
+            if (s0 >= NPIX * 8) continue;
             const int iy = py0 + (p_rc[j] >> 8), ix = px0 + (p_rc[j] & 255);
             const bool in = p_rc[j] != 0xFFFF && iy >= 0 && iy < H && ix >= 0 && ix < W;
             if (in) {
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
                 dst[0] = __builtin_bit_cast(f32x4, h0); dst[1] = __builtin_bit_cast(f32x4, l0);
                 dst[2] = __builtin_bit_cast(f32x4, h1); dst[3] = __builtin_bit_cast(f32x4, l1);
             };
-            for (int e = tid; e < (9 - RW) * 64; e += 512) {
+            for (int e = tid; e < (9 - RW) * 64; e += 256 * NT) {
                 const int ln = e & 63, k = e >> 6;
                 f32x4 d[4];
                 split_tap(k + RW, ln, d);
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
             for (int k = 0; k < RW; ++k) split_tap(k, lane, wres[k]);
         } else if constexpr (CG == 32) {
             const f32x4* src = reinterpret_cast<const f32x4*>(wfrag + (size_t)g * 9 * 64 * 16);
-            for (int e = tid; e < (9 - RW) * 64 * 4; e += 512) {
+            for (int e = tid; e < (9 - RW) * 64 * 4; e += 256 * NT) {
                 const int j = e & 3, ln = (e >> 2) & 63, k = e >> 8;
                 *reinterpret_cast<f32x4*>(bw + ((k * 4 + j) * 64 + ln) * 4) = src[e + RW * 256];
             }
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
                 for (int j = 0; j < NQ; ++j) wres[k][j] = src[(k * 64 + lane) * 4 + j];
         } else {
             const f32x4* src = reinterpret_cast<const f32x4*>(wfrag + (size_t)(2 * g) * 9 * 64 * 4);
-            for (int e = tid; e < (9 - RW) * 2 * 64; e += 512) {
+            for (int e = tid; e < (9 - RW) * 2 * 64; e += 256 * NT) {
                 const int ln = e & 63, j = (e >> 6) & 1, k = e >> 7;
                 *reinterpret_cast<f32x4*>(bw + ((k * 2 + j) * 64 + ln) * 4) = src[(j * 9 + k + RW) * 64 + ln];
             }
@@ -386,8 +393,8 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
             aff_sc[nt] = scale ? *reinterpret_cast<const float4*>(scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
             aff_bi[nt] = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (tid < 4 * pp::CH)                                                                       // the zero pixels
-            reinterpret_cast<float*>(smem + PATCH0)[(tid >> 5) * pp::PATCH_F + pp::NPIX * pp::CH + (tid & 31)] = 0.f;
+        if (tid < 2 * NT * pp::CH)                                                                       // the zero pixels
+            reinterpret_cast<float*>(smem + PATCH0)[(tid >> 5) * PATCH_F + NPIX * pp::CH + (tid & 31)] = 0.f;
         const TileXY T0 = tile_xy(0);
         issue_patch(T0, patch_b0);
         issue_table(T0, tab_b0);
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     //   M(k): 16 (8) MFMAs, nothing else
     //   S(k): one side job: epilogue of the previous tile (0), next tile's coordinates + patch / table DMA (1)
     TileXY cur = tile_xy(0), nxt = cur;                     // tile being computed / tile being prefetched (wave-uniform)
-    unsigned base_cur = patch_b0, base_nxt = patch_b0 + pp::PATCH_B;       // LDS byte offsets of the two patch buffers
+    unsigned base_cur = patch_b0, base_nxt = patch_b0 + PATCH_B;       // LDS byte offsets of the two patch buffers
     unsigned tab_cur = tab_b0, tab_nxt = tab_b0 + pp::TAB_B;               // ... of the two table buffers
     bool have_next = false;
     int it = 0;
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     // 16 channels per group: does any tile of this workgroup hold a far sample?  (one word per tile behind the table, written by the
     // pre-pass; every wave reads them itself: no barrier)
     bool wg_far = true;
-    if constexpr (CG == 16 || PP_SPLIT32) {
+    if constexpr ((CG == 16 || PP_SPLIT32) && NT == 2) {
         const unsigned* tflag = reinterpret_cast<const unsigned*>(table + (size_t)ntiles * pp::NE);
         wg_far = false;
         for (int t = t0 + lane; t < t1; t += 64) {
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void deform_conv3x3_pp_kernel(
     // epilogue stores) before every corner read, even when no lane takes it.  16 channels per group: a second copy of the loop without
     // the far path runs when none of the workgroup's tiles needs it (+8 % at offsets below 1 px).  32 channels per group: the shared
     // register allocation of two copies spills inside the far-capable one (2 px: +9 % time) - one loop there.
-    if constexpr (CG == 16 || PP_SPLIT32) {
+    if constexpr ((CG == 16 || PP_SPLIT32) && NT == 2) {
         if (wg_far) items(std::true_type{});
         else items(std::false_type{});
     } else {
@@ -685,16 +692,27 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<32>()));
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<16>()));
+        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<32, false, pp::PS_WIDE, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<32, pp::PS_WIDE, 1>()));
+        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<16, false, pp::PS_WIDE, 1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<16, pp::PS_WIDE, 1>()));
         attr_set = true;
     }
     const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
     const int items = c / pp::CH;
     const int ntiles = batch * ((ho + 7) / 8) * ((wo + 7) / 8);
+    // stride 2, WD_PP_S2=wide: 21 x 21 patches (no sample of an undeformed tap leaves the patch), one team per workgroup - the patches take
+    // the LDS of the second team.  Measured on MI355X (tools/deform_s2_bench.py, profiles/r04_deform_stride2.txt): res3 205 vs 229 us at
+    // 0.2 px but 261 vs 230 us at 2 px, res4 109 vs 108 / 132 vs 112 us: one wave per SIMD costs what the far path costs -> the default
+    // stays the two-team kernel with 14 x 14 patches placed over the middle of the footprint (pp_origin)
+    static const bool s2_wide = getenv("WD_PP_S2") && getenv("WD_PP_S2")[0] == 'w';
+    const bool wide = stride == 2 && s2_wide;
+    const int teams = wide ? 1 : 2;
     if (!table || stride != 1) {
         void* scratch = nullptr;
         WT_TRY(scratch_table(wd_deform_table_bytes(batch, ho, wo), stream, &scratch));
         hipLaunchKernelGGL(deform_table_kernel, dim3((unsigned)(ntiles < 65535 ? ntiles : 65535)), dim3(pp::NE), 0, stream, offset, batch, h, w,
-                           ho, wo, stride, (uint4*)scratch);
+                           ho, wo, stride, wide ? pp::PS_WIDE : pp::PS, (uint4*)scratch);
         WT_HIP(hipGetLastError());
         table = scratch;
     }
@@ -708,12 +726,18 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
     static const int nsplit_env = getenv("WD_PP_NSPLIT") ? atoi(getenv("WD_PP_NSPLIT")) : 0;    // experiments: fewer workgroups per item
     if (nsplit_env > 0 && nsplit_env < nsplit) nsplit = nsplit_env;
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > (ntiles + 1) / 2) nsplit = (ntiles + 1) / 2;       // at least two tiles (one per team) per workgroup
+    if (nsplit > (ntiles + teams - 1) / teams) nsplit = (ntiles + teams - 1) / teams;       // at least one tile per team
     if (nsplit < 1) nsplit = 1;
     const float* wfrag = packed_weight + (size_t)c * cg * 9;       // lane-major fragment copy (pack_weight_kernel)
     static const bool bf3 = getenv("WD_DEFORM_BF16X3") && getenv("WD_DEFORM_BF16X3")[0] == '1';     // EXPERIMENT: not fp32 (see the kernel's header)
     const dim3 grid((unsigned)(items * nsplit));
-    if (cg == 32 && bf3) {
+    if (wide && cg == 32)
+        hipLaunchKernelGGL((deform_conv3x3_pp_kernel<32, false, pp::PS_WIDE, 1>), grid, dim3(256), (pp::smem_bytes<32, pp::PS_WIDE, 1>()), stream, x,
+                           wfrag, scale, bias, relu, batch, h, w, ho, wo, stride, c, c, nsplit, y, (const uint4*)table);
+    else if (wide)
+        hipLaunchKernelGGL((deform_conv3x3_pp_kernel<16, false, pp::PS_WIDE, 1>), grid, dim3(256), (pp::smem_bytes<16, pp::PS_WIDE, 1>()), stream, x,
+                           wfrag, scale, bias, relu, batch, h, w, ho, wo, stride, c, c, nsplit, y, (const uint4*)table);
+    else if (cg == 32 && bf3) {
         static bool attr3 = false;
         if (!attr3) {
             WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<32, true>),
