@@ -264,11 +264,47 @@ def cpu_baseline_track(ithr, sthr):
     with ThreadPoolExecutor(n_thr) as ex:
         list(ex.map(work, range(n_thr)))
     dtm = time.perf_counter() - t0
-    return dict(value=n_thr * per_thread * 990 / dtm, unit='frames/s', cores=n_thr, kind='port',
-                single_thread=single,
-                sample='oracle/sort_oracle.c (C restatement of tracking/sort): 1 segment x 5 cameras x 198 frames per '
-                       'call; %d calls on one thread (%.0f frames/s), then %d threads x %d calls (one segment per thread, '
-                       'the way the GPU path shards streams)' % (reps, single, n_thr, per_thread))
+    # config 1 at its stated size: ONE segment; its five camera streams are the only independent pieces (ids are offset afterwards),
+    # so the port can use five threads on it, not 128
+    subs = split_streams(packed)
+    reps1 = max(2, int(round(single * 3.0 / 990)))
+
+    def one_stream(sp):
+        for _ in range(reps1):
+            O.track_streams(sp, 2, 0, sthr, ithr)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(len(subs)) as ex:
+        list(ex.map(one_stream, subs))
+    dt1 = time.perf_counter() - t0
+    res = dict(value=n_thr * per_thread * 990 / dtm, unit='frames/s', cores=n_thr, kind='port',
+               single_thread=single, one_segment_one_thread_per_stream=dict(value=reps1 * 990 / dt1, threads=len(subs)),
+               sample='oracle/sort_oracle.c (C restatement of tracking/sort): 1 segment x 5 cameras x 198 frames per '
+                      'call; %d calls on one thread (%.0f frames/s), then %d threads x %d calls (one segment per thread, '
+                      'the way the GPU path shards streams); one segment with one thread per camera stream: %.0f frames/s'
+                      % (reps, single, n_thr, per_thread, reps1 * 990 / dt1))
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_reference_sort_on_stub.json')
+    if os.path.exists(ref):
+        try:
+            res['reference_python_sort'] = dict(json.load(open(ref)), source='profiles/r02_reference_sort_on_stub.json')
+        except ValueError:
+            pass
+    return res
+
+
+def split_streams(packed):
+    """One packed detection set per stream (the CPU port's unit of parallelism inside a segment)."""
+    so, fo = packed['stream_frame_offsets'], packed['frame_det_offsets']
+    out = []
+    for i in range(len(so) - 1):
+        f0, f1 = int(so[i]), int(so[i + 1])
+        d0, d1 = int(fo[f0]), int(fo[f1])
+        sub = {k: packed[k][d0:d1].copy() for k in ('x', 'y', 'w', 'h', 'score', 'category')}
+        sub['frame_det_offsets'] = (fo[f0:f1 + 1] - d0).astype(np.int64)
+        sub['stream_frame_offsets'] = np.asarray([0, f1 - f0], np.int64)
+        sub['clip_w'] = packed['clip_w'][i:i + 1].copy()
+        sub['clip_h'] = packed['clip_h'][i:i + 1].copy()
+        out.append(sub)
+    return out
 
 
 def build_groups(seed, n_images, k_inputs, n_objects=100):
@@ -365,11 +401,27 @@ def cpu_baseline_e2e(pipe, track, height=448, width=640):
         O.track_streams(packed, 2, 0, [0.0] * 4, [0.01, 0.01, 1.0, 0.0])
         t_sort = time.perf_counter() - t0
     ratio = (1920 * 1280) / float(height * width)
-    return dict(value=1.0 / (t_det + t_sort), unit='frames/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 synthetic frame at %dx%d through oracle/detector_ref.py (PyTorch CPU fp32, same parameters) + '
-                       'oracle SORT: detector %.2f s, SORT %.4f s; 1920x1280 has %.2fx the pixels'
-                       % (width, height, t_det, t_sort, ratio),
-                full_res_equivalent=1.0 / (t_det * ratio + t_sort))
+    res = dict(value=1.0 / (t_det + t_sort), unit='frames/s', cores=torch.get_num_threads(), kind='port',
+               sample='1 synthetic frame at %dx%d through oracle/detector_ref.py (PyTorch CPU fp32, same parameters) + '
+                      'oracle SORT: detector %.2f s, SORT %.4f s; 1920x1280 has %.2fx the pixels'
+                      % (width, height, t_det, t_sort, ratio),
+               full_res_equivalent=1.0 / (t_det * ratio + t_sort))
+    # measured once at the real size (tools/cpu_baseline_full.py, committed): how good the pixel-ratio extrapolation is; and the
+    # reference's OWN Python SORT loop on the restated filterpy / sklearn stubs (oracle/time_reference_sort.py)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, key in (('r04_cpu_baseline_full_size.json', 'measured_full_size'), ('r02_reference_sort_on_stub.json', 'reference_python_sort')):
+        path = os.path.join(here, 'profiles', name)
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+            except ValueError:
+                continue
+            if key == 'measured_full_size' and '1920x1280' in d:
+                res[key] = dict(frames_per_s=d['1920x1280']['frames_per_s'], detector_s=d['1920x1280']['detector_s'], threads=d.get('threads'),
+                                time_ratio_full_over_640x448=d.get('measured_time_ratio_full_over_small'), source='profiles/' + name)
+            elif key == 'reference_python_sort':
+                res[key] = dict(d, source='profiles/' + name) if isinstance(d, dict) else d
+    return res
 
 
 def cpu_baseline_train(det, height=160, width=224):

@@ -250,6 +250,38 @@ def test_full_size_frame_properties():
     assert torch.allclose(score * 1e5, torch.round(score * 1e5), atol=1e-6)
 
 
+def test_config4_full_size_tta_x15_hflip_properties():
+    """Config 4's detector pass at its real size: a 1920x1280 frame with --tta x1.5,hflip (the reference's documented run, README.md:37;
+    nn/tta.py:228-267) = one pass over a 2880x1920 image.  Same size-independent invariants as the plain full-size test, on boxes
+    mapped back to the ORIGINAL frame (cx mirrored, coordinates divided by 1.5) - plus: the un-mirrored pass at the same scale finds
+    the mirror image of a mirrored input."""
+    from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det, detections_to_wire
+    from oracle import detector_ref as R
+    m = Detectron2Det(seed=0).eval().cuda()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (1, 3, 1280, 1920), generator=g).float().cuda()
+    (b1, s1, c1), = m.predict_device(x, 1.5, True, False)
+    assert m.last_input_size == (1920, 2880)                                                  # what the detector really saw
+    assert 0 < b1.shape[0] <= 100 and torch.isfinite(b1).all() and torch.isfinite(s1).all()
+    assert (s1 > 0.01).all() and (s1 <= 1).all() and torch.all(s1[:-1] >= s1[1:])
+    # boxes live in the transformed image (2880 x 1920, mirrored)
+    assert (b1[:, 0] >= 0).all() and (b1[:, 1] >= 0).all() and (b1[:, 2] <= 2880).all() and (b1[:, 3] <= 1920).all()
+    assert (b1[:, 2] >= b1[:, 0]).all() and (b1[:, 3] >= b1[:, 1]).all() and set(c1.tolist()) <= {0, 1, 2, 3}
+    for c in range(4):
+        bc = b1[c1 == c].cpu()
+        if len(bc) > 1:
+            assert R.nms_sorted(bc, None, 0.5 + 1e-5).all()
+    # the wire conversion maps them back: integer xywh inside the ORIGINAL 1920 x 1280 frame
+    xywh, score, cat = detections_to_wire(b1 / 1.5, s1, c1, 1920, 1280)
+    assert torch.equal(xywh, torch.trunc(xywh)) and (xywh[:, 0] + xywh[:, 2] <= 1920 + 1).all() and (xywh[:, 1] + xywh[:, 3] <= 1280 + 1).all()
+    # mirror consistency: hflip of the input followed by the un-flipped x1.5 pass sees exactly the image the flipped pass sees
+    (b2, s2, c2), = m.predict_device(torch.flip(x, [3]), 1.5, False, False)
+    assert abs(b2.shape[0] - b1.shape[0]) <= 2
+    k = min(20, b1.shape[0], b2.shape[0])
+    d = (b1[:k, None, :] - b2[None, :k, :]).abs().sum(-1).min(1).values
+    assert int((d < 0.5).sum()) >= int(0.9 * k), d                                         # same boxes up to library-kernel accumulation order
+
+
 def _random_model_file(tmp_path, seed=0):
     """A {args, kwargs, state_dict} model file in the reference's format (random weights)."""
     from waymo_2d_tracking_amd.detnet import nn as detnn
