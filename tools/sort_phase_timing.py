@@ -5,7 +5,7 @@ import ctypes as C, os, runpy, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.argv = [os.path.join(ROOT, 'bench.py'), '--stage', 'track', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+sys.argv = [os.path.join(ROOT, 'bench.py'), '--stage', 'track', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--segments', os.environ.get('SEGMENTS', '8')]
 try:
     runpy.run_path(sys.argv[0], run_name='__main__')
 except SystemExit:
