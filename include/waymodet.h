@@ -201,6 +201,11 @@ int wd_upsample2x_nhwc_f32(const float* src, int batch, int h, int w, int c, flo
 /* In-place epilogue behind a library GEMM: y[m][n] = act(y[m][n] + bias[n]); y row-major (M,N), N % 4 == 0. */
 int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int relu, void* stream);
 
+/* Backward of the fused epilogue y = act(z * scale[n] + bias[n]) with respect to z (training; what autograd derives from
+ * detectron2's FrozenBatchNorm2d + F.relu_ behind a convolution): g[m][n] = dy[m][n] * (relu ? y[m][n] > 0 : 1) * (scale ? scale[n] : 1).
+ * Row-major (M, N) float32, N % 4 == 0; g may alias dy. */
+int wd_act_bwd_f32(const float* dy, const float* y, const float* scale, long m, int n, int relu, float* g, void* stream);
+
 /* ImageOps.autocontrast(image) of PIL with cutoff 0 - the reference's AutoContrast transform (detnet/trainer/transforms/vision.py:1069-1075,
  * detnet/inference.py:171; README.md:37 runs with --auto-contrast=1) - on an (h, w, 3) uint8 DEVICE image, in place, bit-exact with PIL
  * (per channel lut[v] = clamp(int(v * (255.0 / (hi - lo)) + (-lo * scale)), 0, 255) in float64, identity when hi <= lo).

@@ -157,6 +157,36 @@ def test_training_losses_and_gradients_vs_f64_restatement():
             assert cos > 0.9999, (n, cos)
 
 
+def test_fused_training_epilogues_equal_the_plain_autograd_graph(monkeypatch):
+    """Round 4: FrozenBN affine / bias / residual / ReLU fused into the producing op for training (ops.LinearActFn, the epilogue of the
+    deformable kernel + wd_act_bwd_f32) against the round-3 graph of separate autograd-visible elementwise passes: same losses, same
+    gradients up to the float atomics of the scatter kernels."""
+    from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
+    from waymo_2d_tracking_amd.detnet.nn import training, cascade_rcnn
+    m = Detectron2Det(seed=4).cuda().train()
+    training.set_trainable(m.model)
+    g = torch.Generator().manual_seed(12)
+    img = torch.randint(0, 256, (1, 3, 160, 224), generator=g).float().cuda()
+    gt = torch.tensor([[20., 30., 120., 150.], [100., 40., 215., 155.], [5., 5., 60., 60.]]).cuda()
+    cls = torch.tensor([0, 1, 3]).cuda()
+    cfg = dict(pre_nms=300, post_nms=200, rpn_batch=64, rpn_pos=0.5, roi_batch=128, roi_pos=0.25)
+    out = {}
+    for fused in (False, True):
+        monkeypatch.setattr(cascade_rcnn, 'FUSED_TRAINING_EPILOGUES', fused)
+        for p in m.model.parameters():
+            p.grad = None
+        losses = training.losses(m.model, img, gt, cls, choose=training.first_choice, config=cfg)
+        sum(losses.values()).backward()
+        out[fused] = ({k: float(v) for k, v in losses.items()},
+                      {n: p.grad.clone() for n, p in m.model.named_parameters() if p.requires_grad and p.grad is not None})
+    (l0, g0), (l1, g1) = out[False], out[True]
+    assert set(l0) == set(l1) and set(g0) == set(g1) and len(g0) > 300
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    worst = max(float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-30)) for n in g0)
+    assert worst <= 1e-2, worst
+
+
 def test_training_step_full_size_properties():
     """Config 5 at its stated size (886x1280 crop, train.py:37-47): finite losses, every trainable tensor receives a non-zero
     finite gradient, and two executions of the same step agree (up to the library kernels' atomics: 1e-3 relative on the

@@ -15,12 +15,12 @@ last = marks[(steps - 1) * 3]
 sel = rows[first:last]
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in sel:
-    d = acc[r['Kernel_Name'][:100]]
+    d = acc[r['Kernel_Name'][:400]]
     d[0] += 1; d[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
 tot = sum(v[1] for v in acc.values())
 wall = (int(sel[-1]['End_Timestamp']) - int(sel[0]['Start_Timestamp'])) / 1e6
 print('3 steps: kernel time %.1f ms/step, wall %.1f ms/step' % (tot / 3, wall / 3))
-for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:45]:
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:70]:
     print('%7.2f ms/step %7.1f calls/step %8.1f us  %s' % (v[1] / 3, v[0] / 3, v[1] / v[0] * 1e3, k))
 PY
 cat $R/gpurun_out/train_steady.txt

@@ -125,6 +125,41 @@ extern "C" int wd_bias_relu_f32(float* y, const float* bias, long m, int n, int 
     return WT_OK;
 }
 
+// Backward of y = act(z * scale[col] + bias[col]) with respect to z, given y (training: the FrozenBN affine + ReLU behind a deformable /
+// 1x1 convolution, fused into that op's forward): g[m][n] = dy[m][n] * (y[m][n] > 0 if relu) * scale[n] - one pass instead of
+// threshold_backward + the broadcast multiply of autograd.
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                      const float4* __restrict__ scale, long n4, int cols4, int relu, float4* __restrict__ g) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 d = dy[i];
+        if (relu) {
+            const float4 v = y[i];
+            d.x = v.x > 0.f ? d.x : 0.f; d.y = v.y > 0.f ? d.y : 0.f; d.z = v.z > 0.f ? d.z : 0.f; d.w = v.w > 0.f ? d.w : 0.f;
+        }
+        if (scale) {
+            const float4 sc = scale[i % cols4];
+            d.x *= sc.x; d.y *= sc.y; d.z *= sc.z; d.w *= sc.w;
+        }
+        g[i] = d;
+    }
+}
+
+extern "C" int wd_act_bwd_f32(const float* dy, const float* y, const float* scale, long m, int n, int relu, float* g, void* stream) {
+    WT_TRY(wt::ensure_device());
+    if (m <= 0 || n <= 0) return WT_OK;
+    if ((n & 3) || !dy || !g || (relu && !y) || ((uintptr_t)dy & 15) || ((uintptr_t)g & 15) || (y && ((uintptr_t)y & 15)) ||
+        (scale && ((uintptr_t)scale & 15))) {
+        wt::set_error("wd_act_bwd_f32: N must be a multiple of 4 and pointers 16-byte aligned");
+        return WT_ERR_INVALID;
+    }
+    const long n4 = m * (long)(n / 4);
+    const long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, (const float4*)y, (const float4*)scale, n4, n / 4, relu, (float4*)g);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
 extern "C" int wd_tap_shift_add_f32(const float* partial, int ld, int n_out, const float* bias, int batch, int h, int w,
                                     int stride, float* out, void* stream) {
     WT_TRY(wt::ensure_device());

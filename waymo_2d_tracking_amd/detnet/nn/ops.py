@@ -207,6 +207,15 @@ def bias_relu_(y, bias, relu=True):
     return y
 
 
+def act_bwd(dy, y, scale, relu):
+    """g = dy * (y > 0 if relu) * scale[col] on row-major (M, N) matrices: backward of the fused affine + ReLU epilogue (one pass)."""
+    m, n = dy.shape
+    g = torch.empty_like(dy)
+    _lib.check(_lib.lib().wd_act_bwd_f32(_p(dy), _p(y) if relu else None, _p(scale), C.c_long(m), C.c_int(n), C.c_int(1 if relu else 0), _p(g),
+                                         _stream()), 'wd_act_bwd_f32')
+    return g
+
+
 def upsample2x_nearest(x):
     """F.interpolate(x, scale_factor=2.0, mode='nearest') on a channels_last float32 map (FPN top-down pathway), one HIP kernel
     at HBM speed; returns a channels_last tensor.  Inference only (no autograd)."""
@@ -519,21 +528,29 @@ class DeformConvFn(torch.autograd.Function):
     """y = DeformConv(x, offset; weight), groups / stride / pad as in the forward kernel (no affine, no ReLU)."""
 
     @staticmethod
-    def forward(ctx, x, offset, weight, groups, stride, pad):
+    def forward(ctx, x, offset, weight, groups, stride, pad, scale=None, bias=None, relu=False):
+        """scale / bias / relu: the FrozenBN affine + ReLU of the block, fused into the HIP kernel's epilogue like at inference (round 4:
+        the training graph spent three elementwise passes per block on them, and two more in backward); constants - no gradient."""
         packed = deform_pack_weight(weight, groups)
-        y = deform_conv3x3(x, offset, packed, groups, stride, pad)
-        ctx.save_for_backward(x, offset, weight)
-        ctx.cfg = (groups, stride, pad)
+        y = deform_conv3x3(x, offset, packed, groups, stride, pad, scale, bias, relu)
+        ctx.save_for_backward(x, offset, weight, scale if scale is not None else x.new_empty(0), y if relu else x.new_empty(0))
+        ctx.cfg = (groups, stride, pad, scale is not None, bool(relu))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         """im2col -> two strided-batched library GEMMs per layer -> col2im.  Columns are group-major (G, P, 9*Cg) and dy is
         used through its (G, P, Cout/G) strided view, so no operand or result is permuted / copied in HBM."""
-        x, offset, weight = ctx.saved_tensors
-        groups, stride, pad = ctx.cfg
+        x, offset, weight, scale, y = ctx.saved_tensors
+        groups, stride, pad, has_scale, relu = ctx.cfg
         cout, cg = weight.shape[0], weight.shape[1]
         cog = cout // groups
+        if has_scale or relu:                        # epilogue backward in one pass: dy * (y > 0) * scale
+            dyc = _nhwc(dy)
+            n_, c_, h_, w_ = dyc.shape
+            g = act_bwd(dyc.permute(0, 2, 3, 1).reshape(n_ * h_ * w_, c_), _nhwc(y).permute(0, 2, 3, 1).reshape(n_ * h_ * w_, c_) if relu else None,
+                        scale if has_scale else None, relu)
+            dy = g.view(n_, h_, w_, c_).permute(0, 3, 1, 2)
         dyn = _nhwc(dy).permute(0, 2, 3, 1)
         p = dyn.shape[0] * dyn.shape[1] * dyn.shape[2]
         dyg = dyn.reshape(p, groups, cog).permute(1, 0, 2)                      # (G, P, cog) view, row stride Cout
@@ -546,7 +563,36 @@ class DeformConvFn(torch.autograd.Function):
             wg = weight.view(groups, cog, cg, 9).permute(0, 1, 3, 2).reshape(groups, cog, 9 * cg)   # [g][o][k][i] (small)
             dcol = torch.bmm(dyg, wg)                                           # (G, P, 9*cg)
             dx, doff = deform_col2im(dcol, x, offset, stride, pad, groups)
-        return dx, doff, dw, None, None, None
+        return dx, doff, dw, None, None, None, None, None, None
+
+
+class LinearActFn(torch.autograd.Function):
+    """y = act(a @ W.T + bias [+ residual]) for the training graph (round 4): the forward is the inference path's ONE fused library call
+    (bias + ReLU on the GEMM epilogue, the residual on its beta term) instead of linear + add + relu, the backward masks the incoming
+    gradient once (wd_act_bwd_f32) and hands it to both consumers - the two GEMMs and the residual branch - without a copy."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, residual, relu):
+        if residual is None:
+            y = torch._addmm_activation(bias, a, weight.t(), use_gelu=False) if relu else torch.addmm(bias, a, weight.t())
+        else:
+            r = residual if residual.is_contiguous() else residual.contiguous()
+            y = gemm_lt(a if a.is_contiguous() else a.contiguous(), weight, bias, r, relu)
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(a, weight, y if relu else a.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, weight, y = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        g = act_bwd(dy, y, None, True) if ctx.relu else dy
+        da = g @ weight if ctx.needs_input_grad[0] else None
+        dw = g.t() @ a if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if ctx.needs_input_grad[2] else None
+        dr = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return da, dw, db, dr, None
 
 
 class RoiPoolFpnFn(torch.autograd.Function):
