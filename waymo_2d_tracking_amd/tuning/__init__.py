@@ -28,8 +28,8 @@ def enable_gemm_tuning(online=None, max_tuning_ms=15, max_iterations=30):
         return False
     t = torch.cuda.tunable
     t.enable(True)
-    t.set_max_tuning_duration(max_tuning_ms)
-    t.set_max_tuning_iterations(max_iterations)
+    t.set_max_tuning_duration(int(os.environ.get('WT_TUNE_MS', max_tuning_ms)))           # tools/tune_gemms_long.sh: longer searches
+    t.set_max_tuning_iterations(int(os.environ.get('WT_TUNE_ITERS', max_iterations)))
     # new selections of this process go to a scratch file (never into the package)
     t.set_filename(os.environ.get('WT_TUNABLEOP_OUT', os.path.join(tempfile.gettempdir(), 'wt_tunableop_%d.csv' % os.getpid())))
     loaded = False
