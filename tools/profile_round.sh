@@ -17,5 +17,11 @@ python3 bench.py --stage ensemble > $OUT/ensemble_bench_line.json 2>/dev/null
 python3 bench.py --stage detect --no-cpu-baseline > $OUT/detect_bench_line.json 2>/dev/null
 python3 bench.py --stage decode > $OUT/jpeg_decode_bench_line.json 2>/dev/null
 python3 bench.py --from-jpeg --steps 6 --warmup 2 --no-cpu-baseline > $OUT/e2e_from_jpeg_line.json 2>/dev/null
+python3 bench.py --stage detect --tta x1.5,hflip --auto-contrast --no-cpu-baseline > $OUT/tta_bench_line.json 2>/dev/null
+python3 bench.py --stage track --segments 1 > $OUT/track_seg1_bench_line.json 2>/dev/null
+python3 bench.py --stage track --segments 64 --no-cpu-baseline > $OUT/track_seg64_bench_line.json 2>/dev/null
+WT_FORCE_DIST=1 python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/e2e_rccl_one_rank_line.json 2>/dev/null
+bash tools/hbm_roofline.sh > /dev/null 2>&1; cp gpurun_out/hbm_roofline/summary.json $OUT/hbm_rooflines.json
+bash tools/pmc_traffic.sh > /dev/null 2>&1; cp gpurun_out/prof_e2e/pmc_traffic.json $OUT/e2e_pmc_traffic.json 2>/dev/null
 bash tools/jpeg_profile.sh 20 > /dev/null 2>&1; cp gpurun_out/jpeg/per_image.txt $OUT/jpeg_per_kernel.txt; cp gpurun_out/jpeg/bench.txt $OUT/jpeg_single_call_vs_pil.txt
 for f in $OUT/*_bench_line.json; do echo $f; tail -1 $f | cut -c1-170; done

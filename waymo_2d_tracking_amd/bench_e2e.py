@@ -483,7 +483,7 @@ def _pmc_traffic(tag):
     collected with tools/pmc_traffic.sh - counters cannot be read from inside the timed run); None if not recorded."""
     import json
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-    for fname in ('r03_e2e_pmc_traffic.json', 'r02_e2e_pmc_traffic.json', 'r01_e2e_pmc_traffic.json'):
+    for fname in ('r04_e2e_pmc_traffic.json', 'r03_e2e_pmc_traffic.json', 'r02_e2e_pmc_traffic.json', 'r01_e2e_pmc_traffic.json'):
         try:
             rec = json.load(open(os.path.join(root, fname)))
         except (OSError, ValueError):
