@@ -248,6 +248,47 @@ def test_graph_replay_equals_eager_launches():
         torch.cuda.tunable.enable(saved[2])
 
 
+def test_two_pipelines_in_flight_on_different_streams_equal_serial_runs():
+    """Two detector + tracker instances of one process enqueued on two streams WITHOUT a synchronisation in between (advisor, round 3:
+    the per-stream scratch of the deformable sampling table, the ROIAlign order / flag scratch, the NMS and hipBLASLt workspaces exist
+    for exactly this and no test had both in flight).  Deterministic library kernels, eager launches: the slots and tracker rows must
+    equal those of the same two pipelines run one after the other.  (Captured graphs are replayed on the lane they were captured on:
+    their scratch buffers are baked in per stream.)"""
+    import torch
+    from waymo_2d_tracking_amd.bench_e2e import DetectTrackPipeline
+    saved = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic, torch.cuda.tunable.is_enabled())
+    kw = dict(n_cameras=2, frames_per_camera=2, height=256, width=384, segment_frames=8, distinct_times=4, use_graph=False, deterministic=True)
+
+    def snapshot(p):
+        out = [p.category[:2].clone(), p.xywhs[:2].clone()]
+        for c in range(2):
+            k = int(p.chunk_counts[c, 0])
+            out += [p.out_bbox[c][:k].clone(), p.out_id[c][:k].clone()]
+        return out
+    try:
+        a, b = DetectTrackPipeline(seed=5, **kw), DetectTrackPipeline(seed=6, **kw)
+        for _ in range(2):
+            a.step(True); torch.cuda.synchronize()
+            b.step(True); torch.cuda.synchronize()
+        ref = snapshot(a) + snapshot(b)
+        a2, b2 = DetectTrackPipeline(seed=5, **kw), DetectTrackPipeline(seed=6, **kw)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            with torch.cuda.stream(sa):
+                a2.step(True)
+            with torch.cuda.stream(sb):
+                b2.step(True)                                   # enqueued while a2's kernels are still running
+        torch.cuda.synchronize()
+        got = snapshot(a2) + snapshot(b2)
+        assert int((ref[0] != 0).sum()) > 0 and len(ref) == len(got)
+        for r, g in zip(ref, got):
+            assert r.shape == g.shape and torch.equal(r, g)
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = saved[0], saved[1]
+        torch.cuda.tunable.enable(saved[2])
+
+
 def test_pipeline_with_frames_entering_as_jpeg(oracle):
     """SURVEY 8f rank 3 inside the timed pipeline: the frames of step s + 1 are decoded on the GPU by loader threads while the
     detector works on step s.  Every frame slot holds exactly PIL's decode of its file when its step reads it (checked after
