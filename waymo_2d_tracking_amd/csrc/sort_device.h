@@ -18,6 +18,13 @@ constexpr int kErrCapacity = 4;   // WT_ERR_CAPACITY
 constexpr int kErrNumeric = 5;    // WT_ERR_NUMERIC
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// The tracker is ONE wave: what its phases need between each other is "my earlier LDS / global writes are visible to my other lanes", not a
+// workgroup barrier.  (With helper waves in the workgroup - HelpJob below - a real barrier here would wake them.)
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 __device__ __forceinline__ bool finite_d(double v) { return (v == v) && (v - v == 0.0); }
 
@@ -264,11 +271,31 @@ __device__ __forceinline__ void track_init(const TrackerMem& M, int slot, const 
 // prime index arrays.  Row and column covers live in registers: lane w owns cover word w (64 rows / columns each).
 // All full-matrix passes are row-parallel (lane = row, sequential over the row's columns); the search for "the first
 // uncovered zero in row-major order" is a ballot over rows of (zero word & ~column cover) followed by a ctz.
+// Round 4: HELPER WAVES for one tracker (config 1 at its stated size: 20 trackers on a 256-CU chip).  The tracker stays one wave (wave 0
+// of the workgroup: every serial decision, every compaction by ballot is its own); three more waves of the workgroup sleep at the
+// workgroup barrier and are woken for the phases that are plain data parallelism over the n x m cost matrix - today Munkres step 6
+// (37 % of the tracker's cycles at one segment): wave w takes the columns c = w (mod 4) of every row, the four partial minima and the
+// partial zero bitmaps meet in LDS.  Elementwise the same float operations in the same order: identical matrices, identical bitmaps.
+// Protocol: wave 0 fills the job, sets cmd, wsync() (wakes the helpers), everybody runs help_step6_share (two more barriers inside),
+// wave 0 resets cmd.  Every other wsync() of the single-wave code wakes the helpers for a no-op round trip (cmd = NOP).
+struct HelpJob {
+    int cmd;                       // HELP_NOP / HELP_STEP6 / HELP_EXIT
+    int n, m, ld, changed;
+    float* C;                      // cost matrix (LDS or global: generic pointer)
+    unsigned long long rcov[2], cc[2];
+    float mn_part[4];
+    unsigned long long zpart[4][128][2];
+};
+constexpr int HELP_NOP = 0, HELP_STEP6 = 1, HELP_EXIT = 2;
+constexpr int kHelpWaves = 4;
+__host__ __device__ inline size_t help_lds_bytes() { return (sizeof(HelpJob) + 15) / 16 * 16; }
+
 struct MunkresMem {       // LDS
     int* row_star;        // [n]  column of the star in the row, -1 none
     int* col_star;        // [m]
     int* row_prime;       // [n]
     unsigned long long* zmask;   // [n][W]  bit c of word w: C[r][64 w + c] == 0
+    HelpJob* help;        // helper waves present (workgroup of kHelpWaves waves), nullptr = the tracker is alone
 };
 
 __host__ __device__ inline int munkres_ld(int m) { return m | 1; }
@@ -284,6 +311,7 @@ __device__ __forceinline__ MunkresMem munkres_mem(char* lds, int n_small, int n_
     L.col_star = ip + 2 * n_small;
     const size_t off = (((size_t)(2 * n_small + n_big) * sizeof(int) + 7) / 8) * 8;
     L.zmask = reinterpret_cast<unsigned long long*>(lds + off);
+    L.help = nullptr;
     return L;
 }
 
@@ -291,6 +319,67 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
     const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
     return ((unsigned long long)hi << 32) | lo;
+}
+
+// Step 6 on the columns c = w (mod kHelpWaves): run by wave 0 and by the helpers, same barriers in the same order.  n, m <= 128.
+__device__ __forceinline__ void help_step6_share(HelpJob* J, int w) {
+    const int lane = threadIdx.x & 63;
+    const int n = J->n, m = J->m, ld = J->ld;
+    float* C = J->C;
+    const unsigned long long rc0 = J->rcov[0], rc1 = J->rcov[1], cc0 = J->cc[0], cc1 = J->cc[1];
+    // smallest uncovered value of this wave's columns
+    float mn = __builtin_inff();
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * kWave + lane;
+        const bool unc = (r < n) && !(((j ? rc1 : rc0) >> lane) & 1ull);
+        if (unc) {
+            for (int c = w; c < m; c += kHelpWaves) {
+                const bool ccov = (((c >> 6) ? cc1 : cc0) >> (c & 63)) & 1ull;         // wave-uniform
+                if (ccov) continue;
+                const float v = C[r * ld + c];
+                mn = (v < mn) ? v : mn;
+            }
+        }
+    }
+    mn = wave_min_f(mn);
+    if (lane == 0) J->mn_part[w] = mn;
+    __syncthreads();
+    mn = J->mn_part[0];
+#pragma unroll
+    for (int q = 1; q < kHelpWaves; ++q) { const float o = J->mn_part[q]; mn = (o < mn) ? o : mn; }
+    if (J->changed) {
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * kWave + lane;
+            if (r < n) {
+                const bool rcv = ((j ? rc1 : rc0) >> lane) & 1ull;
+                unsigned long long z0 = 0ull, z1 = 0ull;
+                for (int c = w; c < m; c += kHelpWaves) {
+                    const bool ccov = (((c >> 6) ? cc1 : cc0) >> (c & 63)) & 1ull;
+                    float v = C[r * ld + c];
+                    if (rcv || !ccov) {
+                        if (rcv) v = v + mn;
+                        if (!ccov) v = v - mn;
+                        C[r * ld + c] = v;
+                    }
+                    const unsigned long long bit = (v == 0.f) ? (1ull << (c & 63)) : 0ull;
+                    if (c >> 6) z1 |= bit; else z0 |= bit;
+                }
+                J->zpart[w][r][0] = z0;
+                J->zpart[w][r][1] = z1;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// the life of a helper wave: sleep at the barrier, look at the command, take its share, sleep again
+__device__ __forceinline__ void helper_loop(HelpJob* J, int w) {
+    for (;;) {
+        __syncthreads();
+        const int cmd = J->cmd;
+        if (cmd == HELP_EXIT) return;
+        if (cmd == HELP_STEP6) help_step6_share(J, w);
+    }
 }
 
 #ifdef WT_PHASE_TIMING
@@ -342,7 +431,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
             L.row_prime[r] = -1;
         }
     }
-    __syncthreads();
+    wsync();
     // zero word w of row r (r wave-uniform)
     auto zrow = [&](int r, int w) -> unsigned long long {
         unsigned long long v = 0ull;
@@ -374,7 +463,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
             for (int w = 0; w < WM; ++w) if (w == (first >> 6)) cc[w] |= 1ull << (first & 63);
         }
     }
-    __syncthreads();
+    wsync();
     WT_TICK(6)
     long guard = 0;
     const long guard_max = 64L + 8L * (long)(n + m) * (long)(n + m) * (long)(n + 1);
@@ -419,7 +508,54 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
             }
             if (fr < 0) {
                 WT_TICK(8)
-                if constexpr (WM <= 2) {
+                if constexpr (WM <= 2 && RM <= 2) {
+                if (L.help) {
+                    // helper waves present: the same step on a quarter of the columns per wave (see HelpJob)
+                    HelpJob* J = L.help;
+                    bool any_r = false, any_c = false;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        if (w >= W) continue;
+                        const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                        const unsigned long long valid = (c1 == 64) ? ~0ull : ((1ull << c1) - 1ull);
+                        any_c = any_c || ((~cc[w] & valid) != 0ull);
+                    }
+#pragma unroll
+                    for (int j = 0; j < RM; ++j) {
+                        if (j >= R) continue;
+                        const int r = j * kWave + lane;
+                        any_r = any_r || (__ballot((r < n) && !((rcov[j] >> lane) & 1ull)) != 0ull);
+                    }
+                    if (lane == 0) {
+                        J->n = n; J->m = m; J->ld = ld; J->C = (float*)C; J->changed = (any_r && any_c) ? 1 : 0;
+                        J->rcov[0] = rcov[0]; J->rcov[1] = RM > 1 ? rcov[RM - 1] : 0ull;
+                        J->cc[0] = cc[0]; J->cc[1] = WM > 1 ? cc[WM - 1] : 0ull;
+                        J->cmd = HELP_STEP6;
+                    }
+                    __syncthreads();                    // wakes the helpers
+                    help_step6_share(J, 0);
+                    if (lane == 0) J->cmd = HELP_NOP;
+                    if (any_r && any_c) {
+#pragma unroll
+                        for (int j = 0; j < RM; ++j) {
+                            if (j >= R) continue;
+                            const int r = j * kWave + lane;
+                            if (r < n) {
+#pragma unroll
+                                for (int w = 0; w < WM; ++w) {
+                                    if (w >= W) continue;
+                                    unsigned long long zz = 0ull;
+#pragma unroll
+                                    for (int q = 0; q < kHelpWaves; ++q) zz |= J->zpart[q][r][w];
+                                    z[j][w] = zz;
+                                }
+                            }
+                        }
+                    }
+                    wsync();
+                    WT_TICK(7)
+                    continue;
+                }
                 // (<= 128 columns: ROW-parallel - lane = row, serial over the row's columns; faster for the small LDS-resident matrices of
                 //  the batch stages: 31.7 k vs 19.5 k frames/s on the 1-segment track stage)
                     // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns
@@ -545,7 +681,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
                         }
                     }
                 }
-                __syncthreads();
+                wsync();
                 WT_TICK(7)
                 continue;
             }
@@ -557,7 +693,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
 #pragma unroll
             for (int w = 0; w < WM; ++w) if (w == (sc >> 6)) cc[w] &= ~(1ull << (sc & 63));
         }
-        __syncthreads();
+        wsync();
         // step 5: augmenting path (serial, lane 0); then erase primes
         if (lane == 0) {
             int pr = z0r, pc = z0c;
@@ -570,9 +706,9 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
                 pc = L.row_prime[r2];
             }
         }
-        __syncthreads();
+        wsync();
         for (int r = lane; r < n; r += kWave) L.row_prime[r] = -1;
-        __syncthreads();
+        wsync();
     }
 }
 
@@ -607,7 +743,7 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
             L.row_prime[r] = -1;
         }
     }
-    __syncthreads();
+    wsync();
     // greedy stars in row-major order (serial over rows; lane w keeps column-cover word w)
     unsigned long long colcov = 0ull, rowcov = 0ull;
     for (int r = 0; r < n; ++r) {
@@ -621,7 +757,7 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
             if (lane == (first >> 6)) colcov |= 1ull << (first & 63);
         }
     }
-    __syncthreads();
+    wsync();
     long guard = 0;
     const long guard_max = 64L + 8L * (long)(n + m) * (long)(n + m) * (long)(n + 1);
     for (;;) {
@@ -710,7 +846,7 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
                         }
                     }
                 }
-                __syncthreads();
+                wsync();
                 continue;
             }
             const int sc = uni(L.row_star[fr]);
@@ -719,7 +855,7 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
             if (lane == (fr >> 6)) rowcov |= 1ull << (fr & 63);
             if (lane == (sc >> 6)) colcov &= ~(1ull << (sc & 63));
         }
-        __syncthreads();
+        wsync();
         // step 5: augmenting path (serial, lane 0); then erase primes
         if (lane == 0) {
             int pr = z0r, pc = z0c;
@@ -732,9 +868,9 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
                 pc = L.row_prime[r2];
             }
         }
-        __syncthreads();
+        wsync();
         for (int r = lane; r < n; r += kWave) L.row_prime[r] = -1;
-        __syncthreads();
+        wsync();
     }
 }
 
@@ -782,7 +918,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
     }
     for (int i = lane; i < T; i += kWave) M.trk_match[i] = -1;
     for (int k = lane; k < N; k += kWave) M.det_match[k] = -1;
-    __syncthreads();
+    wsync();
     WT_TICK(0)
     // ---- associate (sort.py:193-230) ----
     if (T > 0 && N > 0) {
@@ -822,7 +958,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
                 }
             }
         }
-        __syncthreads();
+        wsync();
         WT_TICK(1)
         const int rc = in_lds ? munkres_wave(lds_cost, n, m, ld, L) : munkres_wave(M.cost_g, n, m, ld, L);
         if (rc) return rc;
@@ -844,7 +980,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
                 }
             }
         }
-        __syncthreads();
+        wsync();
     }
     WT_TICK(3)
     // ---- update matched tracks (sort.py:270-273) ----
@@ -873,7 +1009,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
         }
     }
     if (T + nb > cap || nb > S.n_free) return kErrCapacity;
-    __syncthreads();
+    wsync();
     for (int k = lane; k < nb; k += kWave) {
         const int slot = M.freel[S.n_free - 1 - k];
         M.order[T + k] = slot;
@@ -889,7 +1025,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
     S.n_free -= nb;
     S.next_local += nb;
     const int T2 = T + nb;
-    __syncthreads();
+    wsync();
     // ---- emit newest first (sort.py:279-290) ----
     int K = 0;
     for (int top = T2; top > 0; top -= kWave) {
@@ -928,7 +1064,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
     S.n_tracks = Tn;
     *n_births = nb;
     *n_rows = K;
-    __syncthreads();
+    wsync();
     WT_TICK(5)
     return 0;
 }

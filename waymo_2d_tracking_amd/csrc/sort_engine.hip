@@ -180,20 +180,31 @@ struct StreamEmit {       // utils.py:38-58 clip / drop / confidence clip, into 
     }
 };
 
-__global__ __launch_bounds__(kWave) void sort_streams_kernel(
+// blockDim.x == kWave: the tracker alone; blockDim.x == kHelpWaves * kWave: waves 1.. are helper waves (sort_device.h HelpJob), launched when the
+// chip has far more CUs than trackers (config 1 at its stated size: 20 trackers)
+__global__ __launch_bounds__(kHelpWaves * kWave) void sort_streams_kernel(
     const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
     const double* __restrict__ h, const double* __restrict__ score, const int32_t* __restrict__ category,
     const int64_t* __restrict__ frame_det_offsets, const int64_t* __restrict__ stream_frame_offsets,
     const double* __restrict__ clip_w, const double* __restrict__ clip_h, int C, int max_age, int min_hits,
     int cap, int capN, int lds_cost_cap, bool have_cost_g, long long n_slots, Workspace ws, State st, int resume) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const unsigned long long lt = lanemask_lt();
     const size_t tk = blockIdx.x;
     const int s = (int)(tk / C);
     const int c = (int)(tk % C) + 1;
     float* lds_cost = reinterpret_cast<float*>(smem);
-    MunkresMem L = munkres_mem(smem + (((size_t)lds_cost_cap * sizeof(float) + 15) / 16) * 16, capN, cap);
+    const size_t mk_off = (((size_t)lds_cost_cap * sizeof(float) + 15) / 16) * 16;
+    MunkresMem L = munkres_mem(smem + mk_off, capN, cap);
+    if (blockDim.x > kWave) {                    // helper waves: the job descriptor lives behind the Munkres state
+        HelpJob* J = reinterpret_cast<HelpJob*>(smem + mk_off + ((wtdev::munkres_lds_bytes(capN, cap) + 15) / 16) * 16);
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (threadIdx.x == 0) J->cmd = HELP_NOP;
+        __syncthreads();
+        if (wave > 0) { helper_loop(J, wave); return; }
+        L.help = J;
+    }
     TrackerMem M = tracker_mem(st, ws, tk, cap, capN, have_cost_g);
     int* det_idx = ws.det_idx + tk * capN;
     TrackerState S = {0, cap, 0, 0};
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
     } else {
         for (int i = lane; i < cap; i += kWave) M.freel[i] = cap - 1 - i;
     }
-    __syncthreads();
+    wsync();
     const double thr_iou = ws.thr_iou[c - 1];
     const double cw = clip_w ? clip_w[s] : 0.0, ch = clip_h ? clip_h[s] : 0.0;
     const long long f0 = stream_frame_offsets[s], f1 = stream_frame_offsets[s + 1];
@@ -243,7 +254,7 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
             created = true;
             first_key = ((f - f0 + frames_before) << 32) | (long long)first_pos;
         }
-        __syncthreads();
+        wsync();
         StreamDets dets = {x, y, w, h, det_idx, d0};
         StreamEmit emit = {cw, ch, ws.irow, ws.ifr, ws.isc, ws.ij, ws.ibf, ws.ibk, ws.igid, n_slots, d0 + lower, (int)f, (int)tk};
         int nb = 0, nr = 0;
@@ -260,6 +271,10 @@ __global__ __launch_bounds__(kWave) void sort_streams_kernel(
         st.first_key[tk] = created ? first_key : -1;
         st.hdr[tk * 4 + 0] = S.n_tracks; st.hdr[tk * 4 + 1] = S.n_free;
         st.hdr[tk * 4 + 2] = S.frame_count; st.hdr[tk * 4 + 3] = S.next_local;
+    }
+    if (L.help) {                                // send the helper waves home
+        if (lane == 0) L.help->cmd = HELP_EXIT;
+        __syncthreads();
     }
 }
 
@@ -451,7 +466,7 @@ int pick_caps(int64_t max_frame_dets, const wt_track_params* p, int* cap, int* c
     if (mk > kLdsMunkresMax) { wt::set_error("frame with %lld detections exceeds the LDS budget of the assignment kernel", (long long)n); return WT_ERR_CAPACITY; }
     int64_t budget = kLdsCostFloats;
     if (n_streams > 0 && n_streams * (int64_t)p->n_classes <= 256) {           // few trackers: what the CU's 160 KiB leave next to the bitmaps
-        const int64_t room = ((int64_t)160 * 1024 - 512 - (int64_t)mk) / 4;
+        const int64_t room = ((int64_t)160 * 1024 - 512 - (int64_t)mk - (int64_t)wtdev::help_lds_bytes() - 16) / 4;
         budget = room < kLdsCostFloatsFew ? room : kLdsCostFloatsFew;
         if (budget < kLdsCostFloats) budget = kLdsCostFloats;
     }
@@ -482,10 +497,15 @@ int run_tracking(int64_t n_dets, const double* x, const double* y, const double*
     WT_HIP(hipMemsetAsync(ws.rcnt, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
     WT_HIP(hipMemsetAsync(ws.rbirths, 0, sizeof(long long) * ((size_t)n_frames * C + 1), stream));
     const unsigned n_trackers = (unsigned)n_streams * (unsigned)C;
+    // helper waves (three more waves per tracker for the data-parallel phases) when every tracker can have a CU to itself anyway;
+    // WT_SORT_HELPERS=0 switches them off (A/B)
+    static const bool helpers_off = getenv("WT_SORT_HELPERS") && getenv("WT_SORT_HELPERS")[0] == '0';
+    const bool helpers = !helpers_off && n_trackers <= 256 && (lds + 15) / 16 * 16 + wtdev::help_lds_bytes() <= (size_t)160 * 1024 - 256;
+    if (helpers) lds = (lds + 15) / 16 * 16 + wtdev::help_lds_bytes();
     if (lds > 48 * 1024)
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_streams_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_streams_kernel, dim3(n_trackers), dim3(kWave), lds, stream, x, y, w, h, score, category,
+    hipLaunchKernelGGL(sort_streams_kernel, dim3(n_trackers), dim3(helpers ? kHelpWaves * kWave : kWave), lds, stream, x, y, w, h, score, category,
                        frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
                        (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws, st, resume);
     WT_HIP(hipGetLastError());
