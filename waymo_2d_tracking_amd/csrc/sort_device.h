@@ -281,12 +281,18 @@ __device__ __forceinline__ void track_init(const TrackerMem& M, int slot, const 
 struct HelpJob {
     int cmd;                       // HELP_NOP / HELP_STEP6 / HELP_EXIT
     int n, m, ld, changed;
-    float* C;                      // cost matrix (LDS or global: generic pointer)
+    float* C;                      // cost matrix (generic pointer) ...
+    int c_lds;                     // ... 1: it lives in LDS (low 32 bits = LDS address), 0: in global memory - the shares use typed pointers
     unsigned long long rcov[2], cc[2];
     float mn_part[4];
     unsigned long long zpart[4][128][2];
+    float rowmin_part[4][128];     // step 1: per wave, the minimum of its columns of every row
+    // IoU matrix (tracker_step): detections through the caller's accessor (copied bytewise), predicted boxes from the tracker's SoA arrays
+    int T, N, transposed, cap;
+    const double* pbox;
+    alignas(8) char dets[64];
 };
-constexpr int HELP_NOP = 0, HELP_STEP6 = 1, HELP_EXIT = 2;
+constexpr int HELP_NOP = 0, HELP_STEP6 = 1, HELP_EXIT = 2, HELP_STEP1 = 3, HELP_IOU = 4;
 constexpr int kHelpWaves = 4;
 __host__ __device__ inline size_t help_lds_bytes() { return (sizeof(HelpJob) + 15) / 16 * 16; }
 
@@ -296,6 +302,7 @@ struct MunkresMem {       // LDS
     int* row_prime;       // [n]
     unsigned long long* zmask;   // [n][W]  bit c of word w: C[r][64 w + c] == 0
     HelpJob* help;        // helper waves present (workgroup of kHelpWaves waves), nullptr = the tracker is alone
+    int cost_in_lds;      // (helper jobs) the cost matrix handed to munkres_wave lives in LDS
 };
 
 __host__ __device__ inline int munkres_ld(int m) { return m | 1; }
@@ -312,6 +319,7 @@ __device__ __forceinline__ MunkresMem munkres_mem(char* lds, int n_small, int n_
     const size_t off = (((size_t)(2 * n_small + n_big) * sizeof(int) + 7) / 8) * 8;
     L.zmask = reinterpret_cast<unsigned long long*>(lds + off);
     L.help = nullptr;
+    L.cost_in_lds = 0;
     return L;
 }
 
@@ -322,10 +330,15 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 }
 
 // Step 6 on the columns c = w (mod kHelpWaves): run by wave 0 and by the helpers, same barriers in the same order.  n, m <= 128.
-__device__ __forceinline__ void help_step6_share(HelpJob* J, int w) {
+using help_lds_f = __attribute__((address_space(3))) float*;
+using help_glb_f = __attribute__((address_space(1))) float*;
+#define HELP_DISPATCH(core, ...) do { if (J->c_lds) core(__VA_ARGS__, (help_lds_f)(uintptr_t)(unsigned)(uintptr_t)J->C); \
+                                      else core(__VA_ARGS__, (help_glb_f)(uintptr_t)J->C); } while (0)
+
+template <class CP>
+__device__ __forceinline__ void help_step6_core(HelpJob* J, int w, CP C) {
     const int lane = threadIdx.x & 63;
     const int n = J->n, m = J->m, ld = J->ld;
-    float* C = J->C;
     const unsigned long long rc0 = J->rcov[0], rc1 = J->rcov[1], cc0 = J->cc[0], cc1 = J->cc[1];
     // smallest uncovered value of this wave's columns
     float mn = __builtin_inff();
@@ -372,13 +385,102 @@ __device__ __forceinline__ void help_step6_share(HelpJob* J, int w) {
     __syncthreads();
 }
 
+__device__ __forceinline__ void help_step6_share(HelpJob* J, int w) { HELP_DISPATCH(help_step6_core, J, w); }
+
+// Step 1 on the columns c = w (mod kHelpWaves): partial row minima, then subtract the row minimum and report the zero bits of the own columns.
+template <class CP>
+__device__ __forceinline__ void help_step1_core(HelpJob* J, int w, CP C) {
+    const int lane = threadIdx.x & 63;
+    const int n = J->n, m = J->m, ld = J->ld;
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * kWave + lane;
+        if (r < n) {
+            // (wave 0 starts from the value of column 0, like the sequential loop: a NaN there propagates, a NaN elsewhere is skipped)
+            float mn = (w == 0) ? C[r * ld] : __builtin_inff();
+            for (int c = w; c < m; c += kHelpWaves) { const float v = C[r * ld + c]; mn = (v < mn) ? v : mn; }
+            J->rowmin_part[w][r] = mn;
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * kWave + lane;
+        if (r < n) {
+            float mn = J->rowmin_part[0][r];
+#pragma unroll
+            for (int q = 1; q < kHelpWaves; ++q) { const float o = J->rowmin_part[q][r]; mn = (o < mn) ? o : mn; }
+            unsigned long long z0 = 0ull, z1 = 0ull;
+            for (int c = w; c < m; c += kHelpWaves) {
+                const float v = C[r * ld + c] - mn;
+                C[r * ld + c] = v;
+                const unsigned long long bit = (v == 0.f) ? (1ull << (c & 63)) : 0ull;
+                if (c >> 6) z1 |= bit; else z0 |= bit;
+            }
+            J->zpart[w][r][0] = z0;
+            J->zpart[w][r][1] = z1;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void help_step1_share(HelpJob* J, int w) { HELP_DISPATCH(help_step1_core, J, w); }
+
+// IoU matrix: wave w takes the tracks t = w (mod kHelpWaves); lane = detection, the wave's tracks are held lane-wise and broadcast by readlane
+// exactly as in the single-wave loop of tracker_step (same iou_det_trk per pair: identical float32 entries)
+template <class Dets, class CP>
+__device__ __forceinline__ void help_iou_core(HelpJob* J, int w, CP C) {
+    const int lane = threadIdx.x & 63;
+    const int T = J->T, N = J->N, ld = J->ld, cap = J->cap;
+    const bool transposed = J->transposed != 0;
+    const double* pbox = J->pbox;
+    Dets dets;
+    __builtin_memcpy(&dets, J->dets, sizeof(Dets));
+    for (int dbase = 0; dbase < N; dbase += kWave) {
+        const int d = dbase + lane;
+        float db[4] = {0.f, 0.f, 0.f, 0.f};
+        if (d < N) dets.get(d, db);
+        for (int tbase = 0; tbase < T; tbase += kWave) {
+            const int tl = tbase + lane;
+            double tbx[4] = {0., 0., 0., 0.};
+            if (tl < T) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tbx[q] = pbox[q * cap + tl];
+            }
+            const int tcnt = (T - tbase) < kWave ? (T - tbase) : kWave;
+            for (int tt = w; tt < tcnt; tt += kHelpWaves) {
+                double tb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long bits = readlane64((unsigned long long)__double_as_longlong(tbx[q]), tt);
+                    tb[q] = __longlong_as_double((long long)bits);
+                }
+                const float v = (float)iou_det_trk(db, tb);
+                if (d < N) {
+                    const int t = tbase + tt;
+                    const int r = transposed ? t : d, c = transposed ? d : t;
+                    C[r * ld + c] = -v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <class Dets>
+__device__ __forceinline__ void help_iou_share(HelpJob* J, int w) {
+    if (J->c_lds) help_iou_core<Dets>(J, w, (help_lds_f)(uintptr_t)(unsigned)(uintptr_t)J->C);
+    else help_iou_core<Dets>(J, w, (help_glb_f)(uintptr_t)J->C);
+}
+
 // the life of a helper wave: sleep at the barrier, look at the command, take its share, sleep again
+template <class Dets>
 __device__ __forceinline__ void helper_loop(HelpJob* J, int w) {
     for (;;) {
         __syncthreads();
         const int cmd = J->cmd;
         if (cmd == HELP_EXIT) return;
         if (cmd == HELP_STEP6) help_step6_share(J, w);
+        else if (cmd == HELP_STEP1) help_step1_share(J, w);
+        else if (cmd == HELP_IOU) help_iou_share<Dets>(J, w);
     }
 }
 
@@ -408,11 +510,38 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
         for (int w = 0; w < WM; ++w) z[j][w] = 0ull;
     WT_T0
     for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;
+    bool step1_done = false;
+    if constexpr (RM <= 2 && WM <= 2) {
+        if (L.help) {                                // helper waves: a quarter of the columns per wave (HelpJob)
+            HelpJob* J = L.help;
+            wsync();                                 // the cost matrix written by this wave is visible to the others behind the barrier
+            if (lane == 0) { J->n = n; J->m = m; J->ld = ld; J->C = (float*)C; J->c_lds = L.cost_in_lds; J->cmd = HELP_STEP1; }
+            __syncthreads();
+            help_step1_share(J, 0);
+#pragma unroll
+            for (int j = 0; j < RM; ++j) {
+                const int r = j * kWave + lane;
+                if (j < R && r < n) {
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        if (w >= W) continue;
+                        unsigned long long zz = 0ull;
+#pragma unroll
+                        for (int q = 0; q < kHelpWaves; ++q) zz |= J->zpart[q][r][w];
+                        z[j][w] = zz;
+                    }
+                    L.row_star[r] = -1;
+                    L.row_prime[r] = -1;
+                }
+            }
+            step1_done = true;
+        }
+    }
     // step 1: subtract row minima and build the zero bitmaps (row-parallel)
 #pragma unroll
     for (int j = 0; j < RM; ++j) {
         const int r = j * kWave + lane;
-        if (j < R && r < n) {
+        if (!step1_done && j < R && r < n) {
             float mn = C[r * ld];
             for (int c = 1; c < m; ++c) { const float v = C[r * ld + c]; mn = (v < mn) ? v : mn; }
 #pragma unroll
@@ -527,7 +656,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
                         any_r = any_r || (__ballot((r < n) && !((rcov[j] >> lane) & 1ull)) != 0ull);
                     }
                     if (lane == 0) {
-                        J->n = n; J->m = m; J->ld = ld; J->C = (float*)C; J->changed = (any_r && any_c) ? 1 : 0;
+                        J->n = n; J->m = m; J->ld = ld; J->C = (float*)C; J->c_lds = L.cost_in_lds; J->changed = (any_r && any_c) ? 1 : 0;
                         J->rcov[0] = rcov[0]; J->rcov[1] = RM > 1 ? rcov[RM - 1] : 0ull;
                         J->cc[0] = cc[0]; J->cc[1] = WM > 1 ? cc[WM - 1] : 0ull;
                         J->cmd = HELP_STEP6;
@@ -928,6 +1057,18 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
         const bool in_lds = (long)n * ld <= (long)lds_cost_cap;
         if (!in_lds && !M.cost_g) return kErrCapacity;
         float* C = in_lds ? lds_cost : M.cost_g;
+        static_assert(sizeof(Dets) <= 64, "HelpJob carries the detection accessor bytewise");
+        if (L.help) {
+            // helper waves: every wave takes a quarter of the tracks (HelpJob); the predicted boxes written above are visible behind the barrier
+            HelpJob* J = L.help;
+            if (lane == 0) {
+                J->T = T; J->N = N; J->transposed = transposed ? 1 : 0; J->cap = cap; J->ld = ld; J->C = C; J->c_lds = in_lds ? 1 : 0; J->pbox = M.pbox;
+                __builtin_memcpy(J->dets, &dets, sizeof(Dets));
+                J->cmd = HELP_IOU;
+            }
+            __syncthreads();
+            help_iou_share<Dets>(J, 0);
+        } else
         // lane = detection (its float32 row is fetched once: two dependent global loads), predicted track boxes are held
         // lane-wise in registers and broadcast one by one with readlane: no memory access in the N x T inner loop
         for (int dbase = 0; dbase < N; dbase += kWave) {
@@ -960,7 +1101,9 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
         }
         wsync();
         WT_TICK(1)
-        const int rc = in_lds ? munkres_wave(lds_cost, n, m, ld, L) : munkres_wave(M.cost_g, n, m, ld, L);
+        MunkresMem L2 = L;
+        L2.cost_in_lds = in_lds ? 1 : 0;
+        const int rc = in_lds ? munkres_wave(lds_cost, n, m, ld, L2) : munkres_wave(M.cost_g, n, m, ld, L2);
         if (rc) return rc;
         WT_TICK(2)
         for (int d = lane; d < N; d += kWave) {

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kHelpWaves * kWave) void sort_streams_kernel(
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if (threadIdx.x == 0) J->cmd = HELP_NOP;
         __syncthreads();
-        if (wave > 0) { helper_loop(J, wave); return; }
+        if (wave > 0) { helper_loop<StreamDets>(J, wave); return; }
         L.help = J;
     }
     TrackerMem M = tracker_mem(st, ws, tk, cap, capN, have_cost_g);
