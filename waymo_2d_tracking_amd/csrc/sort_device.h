@@ -498,7 +498,7 @@ __device__ unsigned long long wt_phase[12];
 // (l, l + 64, ...) in VGPRs and the row / column covers are wave-uniform scalars, so the hot loop of step 4 ("first uncovered
 // zero in row-major order", executed O(n^2) times per frame) runs on ballots / readlanes / scalar bit operations with a single
 // LDS access (row_star) instead of ~6 dependent LDS round trips.
-template <int RM, int WM, class CostPtr>
+template <int RM, int WM, bool HELP = false, class CostPtr>
 __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMem& L) {
     const int lane = threadIdx.x & 63;
     const int W = (m + 63) >> 6, R = (n + 63) >> 6;
@@ -511,7 +511,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
     WT_T0
     for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;
     bool step1_done = false;
-    if constexpr (RM <= 2 && WM <= 2) {
+    if constexpr (HELP && RM <= 2 && WM <= 2) {
         if (L.help) {                                // helper waves: a quarter of the columns per wave (HelpJob)
             HelpJob* J = L.help;
             wsync();                                 // the cost matrix written by this wave is visible to the others behind the barrier
@@ -638,7 +638,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
             if (fr < 0) {
                 WT_TICK(8)
                 if constexpr (WM <= 2 && RM <= 2) {
-                if (L.help) {
+                if (HELP && L.help) {
                     // helper waves present: the same step on a quarter of the columns per wave (see HelpJob)
                     HelpJob* J = L.help;
                     bool any_r = false, any_c = false;
@@ -842,13 +842,13 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
 }
 
 // C: n x m float32 with leading dimension ld (n <= m <= 4096), modified in place.  Returns 0 or kErrNumeric.
-template <class CostPtr>
+template <bool HELP = false, class CostPtr>
 __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L) {
-    if (n <= 128 && m <= 128) return munkres_wave_reg<2, 2>(C, n, m, ld, L);
+    if (n <= 128 && m <= 128) return munkres_wave_reg<2, 2, HELP>(C, n, m, ld, L);
     // round 3: the online detect -> track pipeline keeps (max_age + 2) x 100 track slots per class: up to 100 x 400 problems when the
     // detector's boxes do not persist.  Same code with wider column bitmaps (zero bitmaps 12 VGPR pairs per lane, covers scalar).
     // (<2, 7> and <2, 4> + <2, 7> trip a hipcc 7.2 backend error "V_CMP_NE_U32_e32 0, $src_shared_base"; <2, 6> compiles)
-    if (n <= 128 && m <= 384) return munkres_wave_reg<2, 6>(C, n, m, ld, L);
+    if (n <= 128 && m <= 384) return munkres_wave_reg<2, 6, HELP>(C, n, m, ld, L);     // (HELP: one instantiation per kernel - a shared one is not inlined)
     const int lane = threadIdx.x & 63;
     const int W = (m + 63) >> 6;
     for (int c = lane; c < m; c += kWave) L.col_star[c] = -1;
@@ -1005,7 +1005,7 @@ __device__ int munkres_wave(CostPtr C, int n, int m, int ld, const MunkresMem& L
 
 // One frame of one tracker: sort.py:244-296.  Dets::get(k, float[4]) yields the k-th detection of this class
 // as the float32 row the reference builds (tracker_sort.py:45); Emit receives the rows of sort.py:286-288.
-template <class Dets, class Emit>
+template <bool HELP = false, class Dets, class Emit>
 __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresMem& L, float* lds_cost,
                             int lds_cost_cap, const Dets& dets, int N, double iou_thr, int max_age, int min_hits,
                             int frame_global, long long id_base, Emit& emit, int* n_births, int* n_rows) {
@@ -1058,7 +1058,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
         if (!in_lds && !M.cost_g) return kErrCapacity;
         float* C = in_lds ? lds_cost : M.cost_g;
         static_assert(sizeof(Dets) <= 64, "HelpJob carries the detection accessor bytewise");
-        if (L.help) {
+        if (HELP && L.help) {
             // helper waves: every wave takes a quarter of the tracks (HelpJob); the predicted boxes written above are visible behind the barrier
             HelpJob* J = L.help;
             if (lane == 0) {
@@ -1103,7 +1103,7 @@ __device__ int tracker_step(const TrackerMem& M, TrackerState& S, const MunkresM
         WT_TICK(1)
         MunkresMem L2 = L;
         L2.cost_in_lds = in_lds ? 1 : 0;
-        const int rc = in_lds ? munkres_wave(lds_cost, n, m, ld, L2) : munkres_wave(M.cost_g, n, m, ld, L2);
+        const int rc = in_lds ? munkres_wave<HELP>(lds_cost, n, m, ld, L2) : munkres_wave<HELP>(M.cost_g, n, m, ld, L2);
         if (rc) return rc;
         WT_TICK(2)
         for (int d = lane; d < N; d += kWave) {

@@ -182,7 +182,10 @@ struct StreamEmit {       // utils.py:38-58 clip / drop / confidence clip, into 
 
 // blockDim.x == kWave: the tracker alone; blockDim.x == kHelpWaves * kWave: waves 1.. are helper waves (sort_device.h HelpJob), launched when the
 // chip has far more CUs than trackers (config 1 at its stated size: 20 trackers)
-__global__ __launch_bounds__(kHelpWaves * kWave) void sort_streams_kernel(
+// (HELP = false is the plain single-wave code without a trace of the helper branches: inlined into the hot loops they cost the 64-segment
+//  batch 14 %)
+template <bool HELP>
+__global__ __launch_bounds__(HELP ? kHelpWaves * kWave : kWave) void sort_streams_kernel(
     const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ w,
     const double* __restrict__ h, const double* __restrict__ score, const int32_t* __restrict__ category,
     const int64_t* __restrict__ frame_det_offsets, const int64_t* __restrict__ stream_frame_offsets,
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(kHelpWaves * kWave) void sort_streams_kernel(
     float* lds_cost = reinterpret_cast<float*>(smem);
     const size_t mk_off = (((size_t)lds_cost_cap * sizeof(float) + 15) / 16) * 16;
     MunkresMem L = munkres_mem(smem + mk_off, capN, cap);
-    if (blockDim.x > kWave) {                    // helper waves: the job descriptor lives behind the Munkres state
+    if constexpr (HELP) {                        // helper waves: the job descriptor lives behind the Munkres state
         HelpJob* J = reinterpret_cast<HelpJob*>(smem + mk_off + ((wtdev::munkres_lds_bytes(capN, cap) + 15) / 16) * 16);
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if (threadIdx.x == 0) J->cmd = HELP_NOP;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(kHelpWaves * kWave) void sort_streams_kernel(
         StreamEmit emit = {cw, ch, ws.irow, ws.ifr, ws.isc, ws.ij, ws.ibf, ws.ibk, ws.igid, n_slots, d0 + lower, (int)f, (int)tk};
         int nb = 0, nr = 0;
         int rc = overflow ? WT_ERR_CAPACITY
-                          : tracker_step(M, S, L, lds_cost, lds_cost_cap, dets, N, thr_iou, max_age, min_hits, (int)f,
+                          : tracker_step<HELP>(M, S, L, lds_cost, lds_cost_cap, dets, N, thr_iou, max_age, min_hits, (int)f,
                                          0ll, emit, &nb, &nr);
         if (rc) {
             if (lane == 0) atomicMax(ws.err, rc);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(kHelpWaves * kWave) void sort_streams_kernel(
         st.hdr[tk * 4 + 0] = S.n_tracks; st.hdr[tk * 4 + 1] = S.n_free;
         st.hdr[tk * 4 + 2] = S.frame_count; st.hdr[tk * 4 + 3] = S.next_local;
     }
-    if (L.help) {                                // send the helper waves home
+    if constexpr (HELP) {                        // send the helper waves home
         if (lane == 0) L.help->cmd = HELP_EXIT;
         __syncthreads();
     }
@@ -503,11 +506,16 @@ int run_tracking(int64_t n_dets, const double* x, const double* y, const double*
     const bool helpers = !helpers_off && n_trackers <= 256 && (lds + 15) / 16 * 16 + wtdev::help_lds_bytes() <= (size_t)160 * 1024 - 256;
     if (helpers) lds = (lds + 15) / 16 * 16 + wtdev::help_lds_bytes();
     if (lds > 48 * 1024)
-        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_streams_kernel),
+        WT_HIP(hipFuncSetAttribute(helpers ? reinterpret_cast<const void*>(sort_streams_kernel<true>) : reinterpret_cast<const void*>(sort_streams_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(sort_streams_kernel, dim3(n_trackers), dim3(helpers ? kHelpWaves * kWave : kWave), lds, stream, x, y, w, h, score, category,
-                       frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
-                       (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws, st, resume);
+    if (helpers)
+        hipLaunchKernelGGL(sort_streams_kernel<true>, dim3(n_trackers), dim3(kHelpWaves * kWave), lds, stream, x, y, w, h, score, category,
+                           frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
+                           (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws, st, resume);
+    else
+        hipLaunchKernelGGL(sort_streams_kernel<false>, dim3(n_trackers), dim3(kWave), lds, stream, x, y, w, h, score, category,
+                           frame_det_offsets, stream_frame_offsets, clip_w, clip_h, C, (int)params->max_age,
+                           (int)params->min_hits, cap, capN, lds_cost, cost_g, (long long)n_dets, ws, st, resume);
     WT_HIP(hipGetLastError());
     hipLaunchKernelGGL(rank_classes_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, (int)n_streams, C, ws, st);
     const long long ne = (long long)n_frames * C;
