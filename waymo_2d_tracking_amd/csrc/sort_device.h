@@ -283,7 +283,9 @@ struct HelpJob {
     int n, m, ld, changed;
     float* C;                      // cost matrix (generic pointer) ...
     int c_lds;                     // ... 1: it lives in LDS (low 32 bits = LDS address), 0: in global memory - the shares use typed pointers
-    unsigned long long rcov[2], cc[2];
+    unsigned long long rcov[2], cc[6];
+    int W;                         // column-parallel step 6 (more than 128 columns): words per row ...
+    unsigned long long* zmask;     // ... and where the new zero bitmaps of the rows go ([n][W], MunkresMem::zmask)
     float mn_part[4];
     unsigned long long zpart[4][128][2];
     float rowmin_part[4][128];     // step 1: per wave, the minimum of its columns of every row
@@ -292,7 +294,7 @@ struct HelpJob {
     const double* pbox;
     alignas(8) char dets[64];
 };
-constexpr int HELP_NOP = 0, HELP_STEP6 = 1, HELP_EXIT = 2, HELP_STEP1 = 3, HELP_IOU = 4;
+constexpr int HELP_NOP = 0, HELP_STEP6 = 1, HELP_EXIT = 2, HELP_STEP1 = 3, HELP_IOU = 4, HELP_STEP6C = 5;
 constexpr int kHelpWaves = 4;
 __host__ __device__ inline size_t help_lds_bytes() { return (sizeof(HelpJob) + 15) / 16 * 16; }
 
@@ -386,6 +388,56 @@ __device__ __forceinline__ void help_step6_core(HelpJob* J, int w, CP C) {
 }
 
 __device__ __forceinline__ void help_step6_share(HelpJob* J, int w) { HELP_DISPATCH(help_step6_core, J, w); }
+
+// Step 6 in its COLUMN-parallel form (more than 128 columns: the online pipeline's 100 x 300 problems; lane = column, rows one after the other):
+// wave q takes the rows r = q (mod kHelpWaves); the new zero bitmap words of a row are ballots, written to zmask for wave 0 to pick up.
+template <class CP>
+__device__ __forceinline__ void help_step6c_core(HelpJob* J, int q, CP C) {
+    const int lane = threadIdx.x & 63;
+    const int n = J->n, m = J->m, ld = J->ld, W = J->W;
+    const unsigned long long rc0 = J->rcov[0], rc1 = J->rcov[1];
+    unsigned long long* zmask = J->zmask;
+    float mn = __builtin_inff();
+    for (int r = q; r < n; r += kHelpWaves) {
+        if ((((r >> 6) ? rc1 : rc0) >> (r & 63)) & 1ull) continue;             // covered row (wave-uniform)
+        for (int w = 0; w < W; ++w) {
+            const int c = 64 * w + lane;
+            if (c < m && !((J->cc[w] >> lane) & 1ull)) {
+                const float v = C[r * ld + c];
+                mn = (v < mn) ? v : mn;
+            }
+        }
+    }
+    mn = wave_min_f(mn);
+    if (lane == 0) J->mn_part[q] = mn;
+    __syncthreads();
+    mn = J->mn_part[0];
+#pragma unroll
+    for (int k = 1; k < kHelpWaves; ++k) { const float o = J->mn_part[k]; mn = (o < mn) ? o : mn; }
+    if (J->changed) {
+        for (int r = q; r < n; r += kHelpWaves) {
+            const bool rcv = (((r >> 6) ? rc1 : rc0) >> (r & 63)) & 1ull;        // wave-uniform
+            for (int w = 0; w < W; ++w) {
+                const int c = 64 * w + lane;
+                const bool valid = c < m;
+                const bool ccov = (J->cc[w] >> lane) & 1ull;
+                float v = 1.f;
+                if (valid) {
+                    v = C[r * ld + c];
+                    if (rcv || !ccov) {
+                        if (rcv) v = v + mn;
+                        if (!ccov) v = v - mn;
+                        C[r * ld + c] = v;
+                    }
+                }
+                const unsigned long long zz = __ballot(valid && v == 0.f);
+                if (lane == 0) zmask[(size_t)r * W + w] = zz;
+            }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void help_step6c_share(HelpJob* J, int w) { HELP_DISPATCH(help_step6c_core, J, w); }
 
 // Step 1 on the columns c = w (mod kHelpWaves): partial row minima, then subtract the row minimum and report the zero bits of the own columns.
 template <class CP>
@@ -481,6 +533,7 @@ __device__ __forceinline__ void helper_loop(HelpJob* J, int w) {
         if (cmd == HELP_STEP6) help_step6_share(J, w);
         else if (cmd == HELP_STEP1) help_step1_share(J, w);
         else if (cmd == HELP_IOU) help_iou_share<Dets>(J, w);
+        else if (cmd == HELP_STEP6C) help_step6c_share(J, w);
     }
 }
 
@@ -749,6 +802,49 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
                         }
                     }
                 } else {
+                    if (HELP && L.help && WM <= 6) {
+                        // helper waves: a quarter of the rows per wave (help_step6c_core)
+                        HelpJob* J = L.help;
+                        bool any_r = false, any_c = false;
+#pragma unroll
+                        for (int w = 0; w < WM; ++w) {
+                            if (w >= W) continue;
+                            const int c1 = (m - 64 * w) < 64 ? (m - 64 * w) : 64;
+                            const unsigned long long valid = (c1 == 64) ? ~0ull : ((1ull << c1) - 1ull);
+                            any_c = any_c || ((~cc[w] & valid) != 0ull);
+                        }
+#pragma unroll
+                        for (int j = 0; j < RM; ++j) {
+                            if (j >= R) continue;
+                            const int r = j * kWave + lane;
+                            any_r = any_r || (__ballot((r < n) && !((rcov[j] >> lane) & 1ull)) != 0ull);
+                        }
+                        if (lane == 0) {
+                            J->n = n; J->m = m; J->ld = ld; J->W = W; J->C = (float*)C; J->c_lds = L.cost_in_lds; J->changed = (any_r && any_c) ? 1 : 0;
+                            J->zmask = L.zmask;
+                            J->rcov[0] = rcov[0]; J->rcov[1] = RM > 1 ? rcov[RM - 1] : 0ull;
+#pragma unroll
+                            for (int w = 0; w < WM; ++w) J->cc[w] = cc[w];
+                            J->cmd = HELP_STEP6C;
+                        }
+                        __syncthreads();                    // wakes the helpers
+                        help_step6c_share(J, 0);
+                        if (lane == 0) J->cmd = HELP_NOP;
+                        if (any_r && any_c) {
+#pragma unroll
+                            for (int j = 0; j < RM; ++j) {
+                                if (j >= R) continue;
+                                const int r = j * kWave + lane;
+                                if (r < n) {
+#pragma unroll
+                                    for (int w = 0; w < WM; ++w) if (w < W) z[j][w] = L.zmask[(size_t)r * W + w];
+                                }
+                            }
+                        }
+                        wsync();
+                        WT_TICK(7)
+                        continue;
+                    }
                     // step 6: smallest uncovered value; add it to covered rows, subtract it from uncovered columns.
                     // Round 3: COLUMN-parallel (lane = column, rows visited one after the other): the cost matrix of the online pipeline
                     // (100 x 300, 120 KB) lives in global memory, where the old row-per-lane walk touched 64 cache lines per load
