@@ -20,5 +20,5 @@ names = ['predict', 'iou matrix', 'munkres', 'match filter', 'kalman update', 'b
 tot = v[:6].sum()
 for n, x in zip(names, v[:6]):
     print('%-22s %5.1f %%' % (n, 100 * x / tot))
-for n, i in (('  munkres: step 1 + greedy stars', 6), ('  munkres: steps 3-5 (cover / prime / augment)', 8), ('  munkres: step 6 (adjust)', 7)):
+for n, i in (('  munkres: step 1 (row minima, zero bitmaps)', 9), ('  munkres: greedy stars', 6), ('  munkres: steps 3-5 (cover / prime / augment)', 8), ('  munkres: step 6 (adjust)', 7)):
     print('%-46s %5.1f %%' % (n, 100 * v[i] / tot))

@@ -614,6 +614,7 @@ __device__ int munkres_wave_reg(CostPtr C, int n, int m, int ld, const MunkresMe
         }
     }
     wsync();
+    WT_TICK(9)
     // zero word w of row r (r wave-uniform)
     auto zrow = [&](int r, int w) -> unsigned long long {
         unsigned long long v = 0ull;
