@@ -219,7 +219,8 @@ def stage_track(args, world, rank):
                roofline=dict(bound='latency', kernel='sort_streams_kernel',
                              achieved=sort_flops / (ev_ms / steps * 1e-3) / 1e9, peak=F64_VALU_PEAK_GFLOPS, unit='GFLOP/s f64',
                              traffic=None, hbm_gbs=alg_bytes / (ev_ms / steps * 1e-3) / 1e9,
-                             note='a serial per-frame control loop (Kalman, Munkres) on one wave per tracker: bound by '
+                             note='a serial per-frame control loop (Kalman, Munkres) on one wave per tracker (plus three helper waves for '
+                                  'the IoU matrix and Munkres steps 1 / 6 when there are at most 256 trackers): bound by '
                                   'dependent-instruction / LDS latency, neither by HBM nor by the f64 ALU rate; both '
                                   'fractions are reported for completeness (flops: 21 per IoU pair + 2x7x7x7x3 per '
                                   'Kalman predict/update + Munkres passes not counted)'),
