@@ -312,3 +312,26 @@ def test_mct_c_abi_order_and_errors():
     with pytest.raises(RuntimeError):
         mct.track(bad.tolist(), thr)
     assert _lib.lib().wt_mct_tracker(mct._h, C.c_int(3)) is None
+
+
+@pytest.mark.parametrize('n_segments', [1, 14])
+def test_helper_waves_and_plain_kernel_both_equal_the_oracle(oracle, n_segments):
+    """Round 4: with at most 256 trackers the persistent SORT kernel runs with three helper waves per tracker (IoU matrix, Munkres steps
+    1 / 6 split over four waves: sort_streams_kernel<true>); beyond that the plain single-wave instantiation runs.  1 segment = 5 streams x
+    4 classes = 20 trackers (helpers), 14 segments = 280 trackers (plain): rows, ids, births and boxes identical to the oracle in both."""
+    from waymo_2d_tracking_amd import synthetic as syn
+    from waymo_2d_tracking_amd.tracking import utils as T
+    dets = syn.make_sequence_json(21, n_segments=n_segments, n_frames=12, n_objects=45)
+    predictions = {}
+    for e in dets:
+        seg, fr, cam = e['image_id'].split('/')
+        predictions.setdefault(seg, {}).setdefault(cam, {}).setdefault(int(fr), []).append(
+            {'bbox': e['bbox'], 'score': e['score'], 'category_id': e['category_id']})
+    packed = T.pack_streams(predictions)
+    assert len(packed['stream_frame_offsets']) - 1 == 5 * n_segments
+    sthr, ithr = [0.0, 0.0, 0.0, 0.0], [0.01, 0.01, 0.3, 0.0]
+    out, births = T.track_packed(packed, ithr, 2, 0, sthr)
+    ref = oracle.track_streams(packed, 2, 0, sthr, ithr)
+    assert births == ref['n_births'] and len(out['frame']) == len(ref['frame']) > 0
+    assert np.array_equal(out['object_id'], ref['object_id']) and np.array_equal(out['frame'], ref['frame'])
+    assert np.array_equal(out['bbox'], ref['bbox'])
