@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include <type_traits>
 namespace wtdev {
 
 constexpr int kWave = 64;
@@ -28,13 +29,33 @@ __device__ __forceinline__ void wsync() {
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 __device__ __forceinline__ bool finite_d(double v) { return (v == v) && (v - v == 0.0); }
 
+// Minimum over the 64 lanes, the same value in every lane.  Round 4: DPP lane permutations (VALU speed) instead of six ds_bpermute round trips
+// (~100 cycles each; Munkres step 6 calls this ~26 times per frame).  The inputs are never NaN (the callers' per-lane minima start from +inf
+// and skip NaN entries with `v < mn`), so the order of the comparisons does not matter.
 __device__ __forceinline__ float wave_min_f(float v) {
+#ifdef WT_WAVE_MIN_BPERMUTE
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float u = __shfl_xor(v, o, kWave);
         v = (u < v) ? u : v;
     }
     return v;
+#else
+    auto step = [](float x, auto CTRL, auto ROWMASK) {
+        const int moved = __builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(CTRL)::value, decltype(ROWMASK)::value, 0xF, false);
+        const float u = __int_as_float(moved);
+        return (u < x) ? u : x;
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});      // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});      // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});     // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});     // row_mirror: every lane of a row holds the row's minimum
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});     // row_bcast:15 into rows 1 and 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});     // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#endif
 }
 
 // ---- sort.py:33-47 iou(float32 detection, float64 track) under NumPy-1.x scalar promotion -----------------
