@@ -106,6 +106,18 @@ def test_header_parse_needs_no_gpu():
     assert b'unsupported: RGB-coded' in lib.wt_last_error()
     with pytest.raises(J.Unsupported):
         J.decode_rgb(rgb)
+    # 3x1 sampling factors on all three components (ratio 4:4:4, but 9 blocks per MCU): the candidate kernel starts one decode per
+    # block-in-MCU index with CAND_SLOTS = 8 threads per subsequence - such files go to PIL instead of leaving candidate records unwritten
+    # (advisor, round 3).  The header of a 4:4:4 file is patched; the parser reads nothing else.
+    base = bytearray(JC.encode(JC.synth(32, 48, 2), quality=80, subsampling=0))
+    sof = base.find(b'\xff\xc0')
+    assert sof > 0 and base[sof + 9] == 3
+    for c in range(3):
+        assert base[sof + 11 + 3 * c] == 0x11
+        base[sof + 11 + 3 * c] = 0x31
+    wide = bytes(base)
+    assert lib.wd_jpeg_info(wide, ctypes.c_int64(len(wide)), *[ctypes.byref(v) for v in o]) != 0
+    assert b'unsupported: more than 8 blocks per MCU' in lib.wt_last_error()
 
 
 def test_restatement_on_files_written_by_other_encoders():
