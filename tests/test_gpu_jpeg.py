@@ -48,6 +48,23 @@ def test_decode_rejects_unsupported_flavours_loudly():
         ops.jpeg_decode(b'not a jpeg at all')
     # and the decoder still works afterwards (contexts are released on the error paths)
     assert np.array_equal(ops.jpeg_decode(data).cpu().numpy(), JC.pil_rgb(data))
+    # advisor, round 3: (a) two restart markers in a row = a restart segment without a byte: refused, not decoded to zero blocks
+    rst = JC.encode(JC.synth(64, 96, 2), quality=85, subsampling=2, restart_marker_blocks=2)
+    i = rst.find(b'\xff\xd0')
+    assert i > 0
+    doubled = rst[:i + 2] + b'\xff\xd1' + rst[i + 2:]
+    with pytest.raises(WaymoTrackError, match='empty restart segment|restart markers'):
+        ops.jpeg_decode(doubled)
+    # (b) a few hundred bytes announcing a huge frame with a restart interval of one MCU: refused BEFORE multi-GB buffers are allocated
+    # for segments the file cannot hold (the contexts never shrink)
+    small = bytearray(JC.encode(JC.synth(16, 16, 2), quality=50, subsampling=0, restart_marker_blocks=1))
+    sof = small.find(b'\xff\xc0')
+    small[sof + 5:sof + 9] = (4000).to_bytes(2, 'big') + (4000).to_bytes(2, 'big')          # height, width
+    before = torch.cuda.memory_reserved()
+    with pytest.raises(WaymoTrackError, match='more restart segments than the file holds'):
+        ops.jpeg_decode(bytes(small), out=torch.empty((4000, 4000, 3), dtype=torch.uint8, device='cuda'))
+    assert np.array_equal(ops.jpeg_decode(data).cpu().numpy(), JC.pil_rgb(data))
+    del before
 
 
 def test_image_loader_decodes_jpeg_on_the_gpu(tmp_path):
