@@ -81,6 +81,12 @@ def init_dist(args):
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        # under torchrun (the driver's launch) nobody has given the ranks their own library caches yet: eight ranks in MIOpen find mode
+        # on a fresh box must not share one user database / TunableOp result file (set before the libraries initialise; a value the
+        # user exported wins) - the package's own launcher does the same for its children
+        from waymo_2d_tracking_amd import launcher
+        launcher.adopt_rank_caches(rank, world)
     dist_on = world > 1 or os.environ.get('WT_FORCE_DIST') == '1'       # WT_FORCE_DIST: exercise RCCL with one rank
     torch.cuda.set_device(local if dist_on else 0)
     if dist_on:

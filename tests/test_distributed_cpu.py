@@ -199,6 +199,11 @@ def test_launcher_environment_and_refusal(tmp_path):
     kept = L.rank_environments(2, 23456, base_env={'MIOPEN_USER_DB_PATH': '/x', 'OMP_NUM_THREADS': '3'}, scratch=str(tmp_path / 'cache'))
     assert all(e['MIOPEN_USER_DB_PATH'] == '/x' and e['OMP_NUM_THREADS'] == '3' for e in kept)
     assert 'MIOPEN_USER_DB_PATH' not in L.rank_environments(1, 23456, base_env={})[0]
+    # ranks started by torchrun (the driver's launch) adopt the same per-rank locations in-process; an exported one is left alone
+    env = {'MIOPEN_CUSTOM_CACHE_DIR': '/mine'}
+    assert sorted(L.adopt_rank_caches(3, 8, environ=env, scratch=str(tmp_path / 'tr'))) == ['MIOPEN_USER_DB_PATH', 'WT_TUNABLEOP_OUT']
+    assert env['MIOPEN_CUSTOM_CACHE_DIR'] == '/mine' and 'rank3_of_8' in env['MIOPEN_USER_DB_PATH'] and os.path.isdir(env['MIOPEN_USER_DB_PATH'])
+    assert os.path.isdir(os.path.dirname(env['WT_TUNABLEOP_OUT']))
     # WT_FORCE_DIST=1 without a launcher: only the rendezvous variables are adopted, a user's thread count survives
     saved = dict(os.environ)
     try:

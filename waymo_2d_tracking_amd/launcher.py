@@ -48,6 +48,20 @@ def per_rank_cache_env(rank, n_ranks, scratch=None):
             'WT_TUNABLEOP_OUT': os.path.join(d, 'tunableop.csv')}
 
 
+def adopt_rank_caches(rank, n_ranks, environ=None, scratch=None):
+    """In-process form of per_rank_cache_env for ranks somebody else started (torchrun): point this process's library caches at its
+    own directories before MIOpen / TunableOp initialise.  A location the user exported wins.  Returns the keys it set."""
+    environ = os.environ if environ is None else environ
+    taken = []
+    for k, v in per_rank_cache_env(rank, n_ranks, scratch).items():
+        if k in environ:
+            continue
+        environ[k] = v
+        os.makedirs(os.path.dirname(v) if k == 'WT_TUNABLEOP_OUT' else v, exist_ok=True)
+        taken.append(k)
+    return taken
+
+
 def rank_environments(n_ranks, port, base_env=None, scratch=None):
     """The environment of every child: torchrun's variables for a single node, rendezvous on 127.0.0.1 (the
     container's hostname may not resolve); values the user already set (thread counts, IPC mode, cache locations) win."""
