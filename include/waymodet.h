@@ -186,6 +186,13 @@ int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, 
                          float* col, void* stream);
 int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int groups,
                          int stride, int pad, float* dx, float* doffset, void* stream);
+/* Fused form of the same backward for stride 1 / pad 1 / C_out = C_in / 16 or 32 channels per group (every stride-1 DeformConv of res3 and
+ * res4; round 4): the column slab is never written to HBM.
+ *   wd_deform_dw_f32 : dw (groups, C/groups [o], 9 [tap], C/groups [ci]) = sum over output pixels of dY[p][o] * col[p][tap][ci]
+ *                      (the im2col + dW GEMM pair; dw is overwritten).  dy (N,H,W,C) NHWC. */
+size_t wd_deform_dw_scratch_floats(int batch, int h, int w, int c, int groups);     /* per-workgroup partial sums (reduced by a second launch) */
+int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, int batch, int h, int w, int c, int groups, float* scratch, float* dw,
+                     void* stream);
 
 /* 3x3 convolution (pad 1) with few output channels as "library GEMM + shift-add" (the 18-channel offset conv in front of
  * every DeformConv, job.log:412): partial (N,H,W,ld) holds, per INPUT pixel, partial[tap*n_out + n] = sum_c x[c]*w[n][c][tap]

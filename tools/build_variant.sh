@@ -7,7 +7,7 @@ mkdir -p variants
 unit=${3:-det_deform_pp.hip}
 base=${unit%.hip}
 extra=""
-case $unit in det_deform_pp.hip) extra="-fno-slp-vectorize";; det_gemm.hip|det_backward.hip) extra="-munsafe-fp-atomics";; sort_*|ensemble.hip|det_tail.hip|det_preprocess.hip) extra="-ffp-contract=off";; esac
+case $unit in det_deform_pp.hip) extra="-fno-slp-vectorize";; det_gemm.hip|det_backward.hip|det_deform_bwd.hip) extra="-munsafe-fp-atomics";; sort_*|ensemble.hip|det_tail.hip|det_preprocess.hip) extra="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math $extra $2 -c $unit -o variants/${base}_$1.o
 objs=$(ls *.o | grep -v "^${base}.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/lib_$1.so $objs variants/${base}_$1.o

@@ -8,7 +8,9 @@ from waymo_2d_tracking_amd.detnet.nn import ops
 
 C, G = 1024, 32
 w = (torch.randn(C, C // G, 3, 3, device='cuda') * 0.05).requires_grad_(True)
-for (H, W) in ((56, 80), (28, 80), (14, 80), (112, 80)):
+import os as _os
+SIZES = ((56, 80),) if _os.environ.get('DBW_ONE') == '1' else ((56, 80), (28, 80), (14, 80), (112, 80))
+for (H, W) in SIZES:
     x = torch.randn(1, C, H, W, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
     off = (torch.randn(1, 18, H, W, device='cuda') * 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     dy = torch.randn(1, C, H, W, device='cuda').contiguous(memory_format=torch.channels_last)

@@ -77,7 +77,8 @@ def lib():
         for name in ('wt_track_streams_workspace', 'wt_ensemble_groups_workspace', 'wt_track_state_bytes',
                      'wt_track_chunk_workspace'):
             getattr(_lib, name).restype = C.c_size_t
-        for name in ('wd_workspace_bytes', 'wd_nms_workspace', 'wd_rpn_topk_workspace', 'wd_gemm_nt_workspace', 'wd_deform_table_bytes'):
+        for name in ('wd_workspace_bytes', 'wd_nms_workspace', 'wd_rpn_topk_workspace', 'wd_gemm_nt_workspace', 'wd_deform_table_bytes',
+                     'wd_deform_dw_scratch_floats'):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_size_t
     return _lib

@@ -40,6 +40,7 @@ UNITS = {
     'jpeg_decode.hip': [],
     'det_tail.hip': ['-ffp-contract=off'],
     'det_backward.hip': ['-munsafe-fp-atomics'],
+    'det_deform_bwd.hip': ['-munsafe-fp-atomics'],     # fused deformable backward: global float atomics for the dW / dX / dOffset partial sums
 }
 
 

@@ -313,7 +313,11 @@ __global__ __launch_bounds__(256) void deform_col2im_dx_gather_kernel(const floa
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc += wv[u] * g[u];
         }
+#ifdef WD_DXG_NOATOMIC        // experiments: what do the global atomics cost? (results are wrong)
+        dx[((size_t)(tn * H + iy) * W + ix) * C + c0 + lane] = acc;
+#else
         atomicAdd(&dx[((size_t)(tn * H + iy) * W + ix) * C + c0 + lane], acc);
+#endif
     }
     if (n_global) {                            // large offsets: per-corner global atomics for the flagged samples only
         for (int e = wave; e < BNE; e += 4) {

@@ -524,6 +524,29 @@ def deform_col2im(dcol, x, offset, stride=1, pad=1, groups=1):
     return dx, doff
 
 
+FUSED_DEFORM_BACKWARD = os.environ.get('WD_FUSED_DEFORM_BWD', '1') != '0'     # A/B switch: 0 = the im2col / GEMM / col2im form for every layer
+
+
+def fused_deform_backward_supported(c, cout, groups, stride, pad):
+    """The fused kernels (csrc/det_deform_bwd.hip) cover the stride-1 DeformConvs of res3 / res4: 16 or 32 channels per group."""
+    return FUSED_DEFORM_BACKWARD and stride == 1 and pad == 1 and c == cout and c % groups == 0 and c // groups in (16, 32)
+
+
+def deform_dw(x, offset, dy_nhwc, groups):
+    """dW as (groups, C/groups [o], 9, C/groups [ci]) from x, offset and dy (N,H,W,C contiguous) in one launch: the columns are blended
+    per tile in registers and consumed by the MFMAs directly (wd_deform_dw_f32)."""
+    x = _nhwc(x); offset = _nhwc(offset)
+    n, c, h, w = x.shape
+    cg = c // groups
+    dw = torch.empty((groups, cg, 9, cg), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    scratch = torch.empty(L.wd_deform_dw_scratch_floats(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups)), dtype=torch.float32,
+                          device=x.device)
+    _lib.check(L.wd_deform_dw_f32(_p(x), _p(offset), _p(dy_nhwc), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups),
+                                  _p(scratch), _p(dw), _stream()), 'wd_deform_dw_f32')
+    return dw
+
+
 class DeformConvFn(torch.autograd.Function):
     """y = DeformConv(x, offset; weight), groups / stride / pad as in the forward kernel (no affine, no ReLU)."""
 
@@ -555,9 +578,13 @@ class DeformConvFn(torch.autograd.Function):
         p = dyn.shape[0] * dyn.shape[1] * dyn.shape[2]
         dyg = dyn.reshape(p, groups, cog).permute(1, 0, 2)                      # (G, P, cog) view, row stride Cout
         dx = doff = dw = None
+        fused = fused_deform_backward_supported(x.shape[1], cout, groups, stride, pad)
         if ctx.needs_input_grad[2]:
-            col = deform_im2col(x, offset, stride, pad, groups).view(groups, p, 9 * cg)
-            dwg = torch.bmm(dyg.transpose(1, 2), col)                           # (G, cog, 9*cg): [g][o][k][i]
+            if fused:
+                dwg = deform_dw(x, offset, dyn.contiguous(), groups)
+            else:
+                col = deform_im2col(x, offset, stride, pad, groups).view(groups, p, 9 * cg)
+                dwg = torch.bmm(dyg.transpose(1, 2), col)                       # (G, cog, 9*cg): [g][o][k][i]
             dw = dwg.view(groups, cog, 9, cg).permute(0, 1, 3, 2).reshape(cout, cg, 3, 3)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wg = weight.view(groups, cog, cg, 9).permute(0, 1, 3, 2).reshape(groups, cog, 9 * cg)   # [g][o][k][i] (small)
