@@ -236,6 +236,361 @@ __global__ __launch_bounds__(256) void deform_dw_reduce_kernel(const float* __re
     dw[(((size_t)g * CG + o) * 9 + 3 * wave + t) * CG + ci] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// dX and dOffset.  Three launches per layer:
+//   deform_bwd_tables_kernel : per 8x8 tile, from the offsets only (shared by all groups): the sampling table, the INVERTED table - for
+//     every pixel of the 14x14 input patch the list of (sample, corner) pairs that touch it with a non-zero weight (count with LDS integer
+//     atomics, scan, fill) - and the patch pixels ordered by list length (so that the lanes of a wave gather lists of similar length);
+//   deform_dxoff_kernel      : persistent workgroups (6 waves) over (tile, group) items.  Per item: the group's input patch -> LDS;
+//     dcol^T = W^T dY^T on the MFMAs (A = packed weights from L2, B = dY from global memory, K = output channels of the group): a lane
+//     ends up with 4 consecutive input channels of ITS pixel and tap, so the four corners it needs for dOffset are four ds_read_b128 and
+//     the fragment goes to LDS as one ds_write_b128; then every patch pixel sums its list out of LDS (4 lanes x 4 channels per pixel)
+//     and issues ONE global float atomic per (patch pixel, channel) - the patches of neighbouring tiles overlap.  dcol lives in LDS for 16
+//     channels x 576 samples at a time (36 KB): two workgroups per CU.  dOffset accumulates in registers over the groups of an item range
+//     and is added to global memory once per tile and workgroup.
+//   deform_bwd_far_kernel    : the samples whose corners leave the patch (zero-weight in the kernel above), one wave per (sample, group),
+//     plain dot products and per-corner atomics; exits at once for tiles without such samples.
+// (LDS float atomics run at ~194 cycles per wave instruction on gfx950 (tools/micro/lds_atomic_rate.hip) - a scatter into an LDS patch
+// accumulator is not an option; coalesced global float atomics cost ~5 us per 14 M, measured on det_backward.hip's gather kernel.)
+namespace tt {                             // per-tile tables in global memory (byte offsets); the first LDS_BYTES are copied to LDS as they are
+constexpr int TAB = 0;                     // uint4[576]  sampling entries, index tap * 64 + pixel
+constexpr int INV = TAB + fb::NE * 16;     // u16[2304]   (row << 2 | corner), grouped by patch pixel
+constexpr int START = INV + 2304 * 2;      // u16[200]    list of patch pixel pp = inv[start[pp] .. start[pp + 1])
+constexpr int ORDER = START + 400;         // u16[200]    patch pixels by descending list length
+constexpr int LDS_BYTES = ORDER + 400;     // 14 624
+constexpr int FARPOS = LDS_BYTES;          // u32[576]
+constexpr int NFAR = FARPOS + fb::NE * 4;  // u32
+constexpr int BYTES = NFAR + 32;           // 16 960
+}  // namespace tt
+
+template <int CG>
+__global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __restrict__ offset, int batch, int H, int W, unsigned char* __restrict__ tbl) {
+    __shared__ uint4 tab[fb::NE];
+    __shared__ unsigned farpos[fb::NE];
+    __shared__ int cnt[fb::NPIX], start[fb::NPIX + 1], cursor[fb::NPIX], hist[64], hcur[64];
+    __shared__ unsigned short inv[2304], order[fb::NPIX];
+    __shared__ int nfar;
+    constexpr unsigned PB = CG * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const int tile = blockIdx.x;
+    const int tn = tile / (tiles_y * tiles_x), trem = tile - tn * tiles_y * tiles_x;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    for (int i = tid; i < fb::NPIX; i += 256) cnt[i] = 0;
+    if (tid < 64) hist[tid] = 0;
+    if (tid == 0) nfar = 0;
+    __syncthreads();
+    // which corners of entry e take part in the dx gather: inside the image, non-zero weight
+    auto corners = [&](const uint4 e, unsigned (&pp)[4], bool (&use)[4]) {
+        const float lh = __uint_as_float(e.z), lw = __uint_as_float(e.w), uh = 1.f - lh, uw = 1.f - lw;
+        const float wq[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
+        pp[0] = (e.x & 0xFFFFu) / PB; pp[1] = (e.x >> 16) / PB; pp[2] = (e.y & 0xFFFFu) / PB; pp[3] = (e.y >> 16) / PB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = pp[q] / fb::PS, cc = pp[q] - r * fb::PS;
+            const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + cc;
+            use[q] = pp[q] != (unsigned)fb::ZERO && wq[q] != 0.f && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        }
+    };
+    for (int e = tid; e < fb::NE; e += 256) {
+        const int p = e / 9, k = e - 9 * p;
+        const int yy = p >> 3, xx = p & 7, oy = 8 * ty + yy, ox = 8 * tx + xx;
+        const bool in = oy < H && ox < W;
+        float2 ov = make_float2(0.f, 0.f);
+        if (in) ov = *reinterpret_cast<const float2*>(offset + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * k);
+        const int kh = k / 3;
+        unsigned far;
+        const uint4 en = fb_entry<CG>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, H, W, far);
+        tab[k * 64 + p] = en;
+        farpos[k * 64 + p] = far;
+        if (far) atomicAdd(&nfar, 1);
+        unsigned pp[4]; bool use[4];
+        corners(en, pp, use);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (use[q]) atomicAdd(&cnt[pp[q]], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {                           // exclusive scan of the 196 counts (4 per lane + wave scan)
+        int c[4], s4 = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = lane * 4 + u;
+            c[u] = idx < fb::NPIX ? cnt[idx] : 0;
+            s4 += c[u];
+        }
+        int inc = s4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        int base = inc - s4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = lane * 4 + u;
+            if (idx < fb::NPIX) { start[idx] = base; cursor[idx] = base; }
+            base += c[u];
+        }
+        if (lane == 63) start[fb::NPIX] = inc;
+    }
+    for (int i = tid; i < fb::NPIX; i += 256) atomicAdd(&hist[cnt[i] < 63 ? cnt[i] : 63], 1);
+    __syncthreads();
+    if (wave == 0) {                           // longest lists first: hcur[c] = number of patch pixels with a longer list
+        const int h = hist[lane];
+        int inc = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_down(inc, o, 64);
+            if (lane + o < 64) inc += t;
+        }
+        hcur[lane] = inc - h;
+    }
+    for (int row = tid; row < fb::NE; row += 256) {
+        unsigned pp[4]; bool use[4];
+        corners(tab[row], pp, use);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (use[q]) inv[atomicAdd(&cursor[pp[q]], 1)] = (unsigned short)((row << 2) | q);
+    }
+    __syncthreads();
+    for (int i = tid; i < fb::NPIX; i += 256) order[atomicAdd(&hcur[cnt[i] < 63 ? cnt[i] : 63], 1)] = (unsigned short)i;
+    __syncthreads();
+    unsigned char* out = tbl + (size_t)tile * tt::BYTES;
+    for (int i = tid; i < fb::NE; i += 256) {
+        reinterpret_cast<uint4*>(out + tt::TAB)[i] = tab[i];
+        reinterpret_cast<unsigned*>(out + tt::FARPOS)[i] = farpos[i];
+    }
+    for (int i = tid; i < 2304; i += 256) reinterpret_cast<unsigned short*>(out + tt::INV)[i] = i < start[fb::NPIX] ? inv[i] : (unsigned short)0;
+    for (int i = tid; i < 200; i += 256) {
+        reinterpret_cast<unsigned short*>(out + tt::START)[i] = (unsigned short)(i <= fb::NPIX ? start[i] : 0);
+        reinterpret_cast<unsigned short*>(out + tt::ORDER)[i] = i < fb::NPIX ? order[i] : (unsigned short)0;
+    }
+    if (tid == 0) *reinterpret_cast<unsigned*>(out + tt::NFAR) = (unsigned)nfar;
+}
+
+// weight (C_out, CG, 3, 3) OIHW -> MFMA A-fragment order: wpk[g][tap][mt][lane = 16 j + n][s] = W[g CG + (CG / 4) j + s][mt 16 + n][tap]
+template <int CG>
+__global__ __launch_bounds__(256) void deform_bwd_pack_weight_kernel(const float* __restrict__ w, int G, float* __restrict__ wpk) {
+    constexpr int MT = CG / 16, KS = CG / 4;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= G * 9 * CG * CG) return;
+    const int s = e % KS;
+    int q = e / KS;
+    const int lane = q & 63; q >>= 6;
+    const int mt = q % MT; q /= MT;
+    const int tap = q % 9, g = q / 9;
+    const int o = KS * (lane >> 4) + s, ci = mt * 16 + (lane & 15);
+    wpk[e] = w[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
+}
+
+template <int CG> constexpr size_t dxoff_smem_bytes() { return (size_t)(fb::NPIX + 1) * CG * 4 + fb::NE * 16 * 4 + tt::LDS_BYTES; }
+
+template <int CG>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void deform_dxoff_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ wpk,
+                                                           const unsigned char* __restrict__ tbl, int batch, int H, int W, int C, int items_total,
+                                                           float* __restrict__ dx, float* __restrict__ doff) {
+    constexpr int MT = CG / 16, KS = CG / 4, KQ = KS / 4;       // k-steps of 4 output channels; float4s per operand fragment
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                                   // [197][CG]
+    float* dc = xs + (fb::NPIX + 1) * CG;                                         // [576 rows][16 channels], 16-byte slots XOR-swizzled by row
+    unsigned char* tl = reinterpret_cast<unsigned char*>(dc + fb::NE * 16);       // the tile's tables (tt:: layout)
+    const uint4* tab = reinterpret_cast<const uint4*>(tl + tt::TAB);
+    const unsigned short* inv = reinterpret_cast<const unsigned short*>(tl + tt::INV);
+    const unsigned short* start = reinterpret_cast<const unsigned short*>(tl + tt::START);
+    const unsigned short* order = reinterpret_cast<const unsigned short*>(tl + tt::ORDER);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, j = lane >> 4;
+    const int kh = wave % 3, half = wave / 3;
+    const int G = C / CG;
+    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const long i0 = (long)blockIdx.x * items_total / gridDim.x, i1 = (long)(blockIdx.x + 1) * items_total / gridDim.x;
+    int cur_tile = -1, tn = 0, ty = 0, tx = 0;
+    float od[3][2][2];
+    if (tid < CG) xs[fb::ZERO * CG + tid] = 0.f;
+
+    // dOffset of the finished tile: the four channel quarters (j) of every (pixel, tap) meet in LDS, one global atomic per value
+    auto flush = [&]() {
+        __syncthreads();
+        float* sc = dc;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) sc[((wave * 12) + (t * 2 + p2) * 2 + d) * 64 + lane] = od[t][p2][d];
+        __syncthreads();
+        for (int i = tid; i < 64 * 18; i += 384) {
+            const int pixel = i / 18, c18 = i - pixel * 18;
+            const int tap = c18 >> 1, d = c18 & 1, fkh = tap / 3, t = tap - 3 * fkh;
+            const int pt = pixel >> 4, pn = pixel & 15;
+            const float* q = sc + (((pt >> 1) * 3 + fkh) * 12 + (t * 2 + (pt & 1)) * 2 + d) * 64 + pn;
+            const float v = (q[0] + q[16]) + (q[32] + q[48]);
+            const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);
+            if (oy < H && ox < W) atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + c18, v);
+        }
+    };
+
+    for (long item = i0; item < i1; ++item) {
+        const int tile = (int)(item / G), g = (int)(item - (long)tile * G);
+        if (tile != cur_tile) {
+            if (cur_tile >= 0) flush();
+            __syncthreads();
+            const uint4* src = reinterpret_cast<const uint4*>(tbl + (size_t)tile * tt::BYTES);
+            for (int i = tid; i < tt::LDS_BYTES / 16; i += 384) reinterpret_cast<uint4*>(tl)[i] = src[i];
+            cur_tile = tile;
+            tn = tile / (tiles_y * tiles_x);
+            const int trem = tile - tn * tiles_y * tiles_x;
+            ty = trem / tiles_x; tx = trem - ty * tiles_x;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) od[t][p2][0] = od[t][p2][1] = 0.f;
+        }
+        __syncthreads();                                   // the previous item's gather is done with xs / dc
+        {
+            constexpr int Q = CG / 4;
+            for (int i = tid; i < fb::NPIX * Q; i += 384) {
+                const int pp = i / Q, q = i - pp * Q;
+                const int r = pp / fb::PS;
+                const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + (pp - r * fb::PS);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    v = *reinterpret_cast<const f32x4*>(x + ((size_t)(tn * H + iy) * W + ix) * C + g * CG + q * 4);
+                *reinterpret_cast<f32x4*>(xs + pp * CG + q * 4) = v;
+            }
+        }
+        // B fragments: dY[pixel (2 half + p2) 16 + n][o = KS j + s]
+        f32x4 bq[2][KQ];
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            const int pixel = (2 * half + p2) * 16 + n;
+            const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);
+            const bool in = oy < H && ox < W;
+#pragma unroll
+            for (int u = 0; u < KQ; ++u) {
+                bq[p2][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (in) bq[p2][u] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(tn * H + oy) * W + ox) * C + g * CG + KS * j + 4 * u);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int mt = 0; mt < MT; ++mt) {
+            const char* cb = reinterpret_cast<const char*>(xs + mt * 16 + 4 * j);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int tap = 3 * kh + t;
+                f32x4 aq[KQ];
+                const f32x4* wp = reinterpret_cast<const f32x4*>(wpk + ((((size_t)g * 9 + tap) * MT + mt) * 64 + lane) * KS);
+#pragma unroll
+                for (int u = 0; u < KQ; ++u) aq[u] = wp[u];
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < KQ; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][v], bq[p2][u][v], acc, 0, 0, 0);
+                    // acc[r] = dcol[pixel][tap][ci = mt 16 + 4 j + r]
+                    const int row = tap * 64 + (2 * half + p2) * 16 + n;
+                    const uint4 e = tab[row];
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(cb + (e.x & 0xFFFFu));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(cb + (e.x >> 16));
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(cb + (e.y & 0xFFFFu));
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(cb + (e.y >> 16));
+                    const float lh = __uint_as_float(e.z), lw = __uint_as_float(e.w), uh = 1.f - lh, uw = 1.f - lw;
+                    // d val / d h = (v2 - v0)(1 - lw) + (v3 - v1) lw ;  d val / d w = (v1 - v0)(1 - lh) + (v3 - v2) lh
+                    const f32x4 gh = (v2 - v0) * uw + (v3 - v1) * lw;
+                    const f32x4 gw = (v1 - v0) * uh + (v3 - v2) * lh;
+                    od[t][p2][0] += (acc[0] * gh[0] + acc[1] * gh[1]) + (acc[2] * gh[2] + acc[3] * gh[3]);
+                    od[t][p2][1] += (acc[0] * gw[0] + acc[1] * gw[1]) + (acc[2] * gw[2] + acc[3] * gw[3]);
+                    *reinterpret_cast<f32x4*>(dc + row * 16 + ((j ^ ((row >> 1) & 3)) << 2)) = acc;
+                }
+            }
+            __syncthreads();
+            // gather: patch pixel pp sums its list; 4 lanes x 4 channels per patch pixel, longest lists first
+            {
+                const int c = tid & 3;
+#pragma unroll 1
+                for (int round = 0; round < 3; ++round) {
+                    const int task = round * 96 + (tid >> 2);
+                    if (task < fb::NPIX) {
+                        const int pp = order[task];
+                        const int n0 = start[pp], n1 = start[pp + 1];
+                        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                        for (int i = n0; i < n1; ++i) {
+                            const unsigned ent = inv[i];
+                            const unsigned row = ent >> 2;
+                            const float2 l = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab + row) + 8);
+                            const float wy = (ent & 2) ? l.x : 1.f - l.x, wx = (ent & 1) ? l.y : 1.f - l.y;
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(dc + row * 16 + ((c ^ ((row >> 1) & 3)) << 2));
+                            a += (wy * wx) * v;
+                        }
+                        if (n1 > n0) {
+                            const int r = pp / fb::PS;
+                            const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + (pp - r * fb::PS);
+                            float* d = dx + ((size_t)(tn * H + iy) * W + ix) * C + g * CG + mt * 16 + 4 * c;
+                            atomicAdd(d + 0, a[0]); atomicAdd(d + 1, a[1]); atomicAdd(d + 2, a[2]); atomicAdd(d + 3, a[3]);
+                        }
+                    }
+                }
+            }
+            if (mt + 1 < MT) __syncthreads();
+        }
+    }
+    if (cur_tile >= 0) flush();
+}
+
+// Samples whose corners are not all inside the tile's patch: dcol row by plain dot products (lane = input channel of the group), per-corner
+// global atomics for dX, wave-reduced dOffset.  grid (tiles, groups); one wave per sample in turn.
+template <int CG>
+__global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const unsigned char* __restrict__ tbl, int batch, int H, int W, int C,
+                                                             float* __restrict__ dx, float* __restrict__ doff) {
+    const unsigned char* tb = tbl + (size_t)blockIdx.x * tt::BYTES;
+    if (*reinterpret_cast<const unsigned*>(tb + tt::NFAR) == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.y;
+    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const int tile = blockIdx.x;
+    const int tn = tile / (tiles_y * tiles_x), trem = tile - tn * tiles_y * tiles_x;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const unsigned* farpos = reinterpret_cast<const unsigned*>(tb + tt::FARPOS);
+    const uint4* tab = reinterpret_cast<const uint4*>(tb + tt::TAB);
+    const bool act = lane < CG;
+    const int ci = act ? lane : 0;
+    for (int row = wave; row < fb::NE; row += 4) {
+        const unsigned far = farpos[row];
+        if (!far) continue;
+        const int tap = row >> 6, pixel = row & 63;
+        const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);        // inside the image (far is only set for such pixels)
+        const float* dyp = dy + ((size_t)(tn * H + oy) * W + ox) * C + g * CG;
+        float gcol = 0.f;
+        for (int o = 0; o < CG; ++o) gcol += dyp[o] * w[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
+        if (!act) gcol = 0.f;
+        const uint4 e = tab[row];
+        const float lh = __uint_as_float(e.z), lw = __uint_as_float(e.w), uh = 1.f - lh, uw = 1.f - lw;
+        const int ih = (int)(far & 0xFFFFu) - 32768, iw = (int)(far >> 16) - 32768;
+        const float wq[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = ih + (q >> 1), xx = iw + (q & 1);
+            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const size_t at = ((size_t)(tn * H + (in ? yy : 0)) * W + (in ? xx : 0)) * C + g * CG + ci;
+            v[q] = in ? x[at] : 0.f;
+            if (in && act && wq[q] != 0.f) atomicAdd(dx + at, wq[q] * gcol);
+        }
+        float dh = gcol * ((v[2] - v[0]) * uw + (v[3] - v[1]) * lw);
+        float dw = gcol * ((v[1] - v[0]) * uh + (v[3] - v[2]) * lh);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { dh += __shfl_xor(dh, o, 64); dw += __shfl_xor(dw, o, 64); }
+        if (lane == 0) {
+            atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap, dh);
+            atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap + 1, dw);
+        }
+    }
+}
+
 int check_fused(const char* who, int c, int groups, int h, int w) {
     const int cg = groups > 0 ? c / groups : 0;
     if (groups < 1 || c % groups || (cg != 16 && cg != 32) || h < 1 || w < 1) {
@@ -280,6 +635,62 @@ int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, int b
     } else {
         hipLaunchKernelGGL(deform_dw_kernel<16>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, batch, h, w, c, slices, scratch);
         hipLaunchKernelGGL(deform_dw_reduce_kernel<16>, dim3((unsigned)nred), dim3(256), 0, st, scratch, groups, slices, dw);
+    }
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+size_t wd_deform_bwd_tables_bytes(int batch, int h, int w) { return (size_t)batch * ((h + 7) / 8) * ((w + 7) / 8) * tt::BYTES; }
+
+int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, const float* weight, int batch, int h, int w, int c, int groups,
+                        unsigned char* tables, float* packed_weight, float* dx, float* doffset, void* stream) {
+    WT_TRY(wt::ensure_device());
+    WT_TRY(check_fused("wd_deform_dxoff_f32", c, groups, h, w));
+    const int cg = c / groups;
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = batch * ((h + 7) / 8) * ((w + 7) / 8);
+    const int items = ntiles * groups;
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        WT_HIP(hipGetDevice(&dev));
+        WT_HIP(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount;
+    }
+    int nwg = 2 * cus;                                       // two workgroups (77 KB of LDS, 6 waves each) per CU, all resident
+    if (const char* e = getenv("WD_DXOFF_WGS")) nwg = atoi(e);
+    if (nwg > items) nwg = items;
+    if (nwg < 1) nwg = 1;
+    WT_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)batch * h * w * c, st));
+    WT_HIP(hipMemsetAsync(doffset, 0, sizeof(float) * (size_t)batch * h * w * 18, st));
+    const int npack = (groups * 9 * cg * cg + 255) / 256;
+    if (cg == 32) {
+        static bool attr = false;
+        if (!attr) {
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_dxoff_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)dxoff_smem_bytes<32>()));
+            attr = true;
+        }
+        hipLaunchKernelGGL(deform_bwd_tables_kernel<32>, dim3((unsigned)ntiles), dim3(256), 0, st, offset, batch, h, w, tables);
+        hipLaunchKernelGGL(deform_bwd_pack_weight_kernel<32>, dim3((unsigned)npack), dim3(256), 0, st, weight, groups, packed_weight);
+        hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, packed_weight, tables, batch, h,
+                           w, c, items, dx, doffset);
+        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, (unsigned)groups), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
+                           dx, doffset);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_dxoff_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)dxoff_smem_bytes<16>()));
+            attr = true;
+        }
+        hipLaunchKernelGGL(deform_bwd_tables_kernel<16>, dim3((unsigned)ntiles), dim3(256), 0, st, offset, batch, h, w, tables);
+        hipLaunchKernelGGL(deform_bwd_pack_weight_kernel<16>, dim3((unsigned)npack), dim3(256), 0, st, weight, groups, packed_weight);
+        hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, packed_weight, tables, batch, h,
+                           w, c, items, dx, doffset);
+        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, (unsigned)groups), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
+                           dx, doffset);
     }
     WT_HIP(hipGetLastError());
     return WT_OK;

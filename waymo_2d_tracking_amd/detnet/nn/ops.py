@@ -527,6 +527,9 @@ def deform_col2im(dcol, x, offset, stride=1, pad=1, groups=1):
 FUSED_DEFORM_BACKWARD = os.environ.get('WD_FUSED_DEFORM_BWD', '1') != '0'     # A/B switch: 0 = the im2col / GEMM / col2im form for every layer
 
 
+FUSED_DEFORM_DXOFF = os.environ.get('WD_FUSED_DEFORM_DXOFF', '1') != '0'       # A/B switch for the dX / dOffset half alone
+
+
 def fused_deform_backward_supported(c, cout, groups, stride, pad):
     """The fused kernels (csrc/det_deform_bwd.hip) cover the stride-1 DeformConvs of res3 / res4: 16 or 32 channels per group."""
     return FUSED_DEFORM_BACKWARD and stride == 1 and pad == 1 and c == cout and c % groups == 0 and c // groups in (16, 32)
@@ -545,6 +548,21 @@ def deform_dw(x, offset, dy_nhwc, groups):
     _lib.check(L.wd_deform_dw_f32(_p(x), _p(offset), _p(dy_nhwc), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups),
                                   _p(scratch), _p(dw), _stream()), 'wd_deform_dw_f32')
     return dw
+
+
+def deform_dxoff(x, offset, dy_nhwc, weight, groups):
+    """(dx (N,C,H,W) channels_last, doffset (N,18,H,W) channels_last) without the dcol slab (wd_deform_dxoff_f32): per tile dcol = dY W on the
+    MFMAs, dOffset from the fragment in registers, dX by a gather over the inverted sampling table out of LDS."""
+    x = _nhwc(x); offset = _nhwc(offset)
+    n, c, h, w = x.shape
+    L = _lib.lib()
+    tables = torch.empty(L.wd_deform_bwd_tables_bytes(C.c_int(n), C.c_int(h), C.c_int(w)), dtype=torch.uint8, device=x.device)
+    packed = torch.empty(weight.numel(), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x, memory_format=torch.channels_last)
+    doff = torch.empty_like(offset, memory_format=torch.channels_last)
+    _lib.check(L.wd_deform_dxoff_f32(_p(x), _p(offset), _p(dy_nhwc), _p(weight.contiguous()), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+                                     C.c_int(groups), _p(tables), _p(packed), _p(dx), _p(doff), _stream()), 'wd_deform_dxoff_f32')
+    return dx, doff
 
 
 class DeformConvFn(torch.autograd.Function):
@@ -586,7 +604,9 @@ class DeformConvFn(torch.autograd.Function):
                 col = deform_im2col(x, offset, stride, pad, groups).view(groups, p, 9 * cg)
                 dwg = torch.bmm(dyg.transpose(1, 2), col)                       # (G, cog, 9*cg): [g][o][k][i]
             dw = dwg.view(groups, cog, 9, cg).permute(0, 1, 3, 2).reshape(cout, cg, 3, 3)
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and fused and FUSED_DEFORM_DXOFF:
+            dx, doff = deform_dxoff(x, offset, dyn.contiguous(), weight, groups)
+        elif ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wg = weight.view(groups, cog, cg, 9).permute(0, 1, 3, 2).reshape(groups, cog, 9 * cg)   # [g][o][k][i] (small)
             dcol = torch.bmm(dyg, wg)                                           # (G, P, 9*cg)
             dx, doff = deform_col2im(dcol, x, offset, stride, pad, groups)
