@@ -25,7 +25,8 @@ constexpr int PS = 14;                 // patch side: 8 + 2 (3x3 footprint) + 2 
 constexpr int NPIX = PS * PS;          // 196; pixel 196 = zeros (samples / pixels outside the image)
 constexpr int ZERO = NPIX;
 constexpr int NE = 64 * 9;             // (pixel, tap) entries per tile
-constexpr unsigned FAR = 0xFFFFFFFFu;  // entry.x of a sample whose corners are not all inside the patch
+constexpr int XPAD = 4;                // deform_dxoff_kernel: floats of padding per patch pixel (a lane reads 16 bytes of ITS pixel's corner: with a
+                                       // pitch of CG floats the 16 lanes of a ds_read_b128 group would share 4 bank slots)
 }  // namespace fb
 
 // Sampling entry of (tile pixel (yy, xx), tap (kh, kw)).  Patch origin = image pixel (8 ty - 3, 8 tx - 3).
@@ -34,10 +35,9 @@ constexpr unsigned FAR = 0xFFFFFFFFu;  // entry.x of a sample whose corners are 
 // A sample whose corners are not all inside the patch ("far", |offset| > ~2 px) points at the zero pixel as well - the main loops stay
 // branch-free - and leaves far = (row + 32768) | (column + 32768) << 16 of its upper-left corner in IMAGE coordinates (otherwise 0) for a
 // second pass that only runs for tiles with such samples.
-template <int CG>
+template <unsigned PB>                     // PB = bytes per patch pixel in the LDS patch buffer
 __device__ __forceinline__ uint4 fb_entry(bool pixel_in_image, int yy, int xx, int kh, int kw, float oy, float ox, int ty, int tx, int H, int W,
                                           unsigned& far) {
-    constexpr unsigned PB = CG * 4;        // bytes per patch pixel
     unsigned c0 = fb::ZERO, c1 = fb::ZERO, c2 = fb::ZERO, c3 = fb::ZERO;
     float lh = 0.f, lw = 0.f;
     far = 0;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void fb_stage(const float* __restrict__ x, const floa
         if (in) ov = *reinterpret_cast<const float2*>(offset + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * k);
         const int kh = k / 3;
         unsigned far;
-        tab[k * 64 + p] = fb_entry<CG>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, H, W, far);
+        tab[k * 64 + p] = fb_entry<CG * 4>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, H, W, far);
         farpos[k * 64 + p] = far;
         if (far) farflag[kh] = 1;
     }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
     __shared__ int cnt[fb::NPIX], start[fb::NPIX + 1], cursor[fb::NPIX], hist[64], hcur[64];
     __shared__ unsigned short inv[2304], order[fb::NPIX];
     __shared__ int nfar;
-    constexpr unsigned PB = CG * 4;
+    constexpr unsigned PB = (CG + fb::XPAD) * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const int tile = blockIdx.x;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
         if (in) ov = *reinterpret_cast<const float2*>(offset + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * k);
         const int kh = k / 3;
         unsigned far;
-        const uint4 en = fb_entry<CG>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, H, W, far);
+        const uint4 en = fb_entry<PB>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, H, W, far);
         tab[k * 64 + p] = en;
         farpos[k * 64 + p] = far;
         if (far) atomicAdd(&nfar, 1);
@@ -384,29 +384,37 @@ __global__ __launch_bounds__(256) void deform_bwd_pack_weight_kernel(const float
     wpk[e] = w[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
 }
 
-template <int CG> constexpr size_t dxoff_smem_bytes() { return (size_t)(fb::NPIX + 1) * CG * 4 + fb::NE * 16 * 4 + tt::LDS_BYTES; }
+// keeps the loads of the next (tap, pixel tile) unit from being hoisted over this one (register pressure: 3 waves per SIMD = 168 VGPRs)
+#define FB_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+#ifndef FB_WAVES
+#define FB_WAVES __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+template <int CG> constexpr size_t dxoff_smem_bytes() { return (size_t)(fb::NPIX + 1) * (CG + fb::XPAD) * 4 + fb::NE * 16 * 4 + tt::LDS_BYTES; }
 
 template <int CG>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void deform_dxoff_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ wpk,
+__global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ wpk,
                                                            const unsigned char* __restrict__ tbl, int batch, int H, int W, int C, int items_total,
                                                            float* __restrict__ dx, float* __restrict__ doff) {
     constexpr int MT = CG / 16, KS = CG / 4, KQ = KS / 4;       // k-steps of 4 output channels; float4s per operand fragment
+    constexpr int XP = CG + fb::XPAD;                           // patch pitch in floats
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* xs = reinterpret_cast<float*>(smem);                                   // [197][CG]
-    float* dc = xs + (fb::NPIX + 1) * CG;                                         // [576 rows][16 channels], 16-byte slots XOR-swizzled by row
+    float* xs = reinterpret_cast<float*>(smem);                                   // [197][XP]
+    float* dc = xs + (fb::NPIX + 1) * XP;                                         // [576 rows][16 channels], 16-byte slots XOR-swizzled by row
     unsigned char* tl = reinterpret_cast<unsigned char*>(dc + fb::NE * 16);       // the tile's tables (tt:: layout)
     const uint4* tab = reinterpret_cast<const uint4*>(tl + tt::TAB);
     const unsigned short* inv = reinterpret_cast<const unsigned short*>(tl + tt::INV);
     const unsigned short* start = reinterpret_cast<const unsigned short*>(tl + tt::START);
     const unsigned short* order = reinterpret_cast<const unsigned short*>(tl + tt::ORDER);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, j = lane >> 4;
+    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int kh = wave % 3, half = wave / 3;
     const int G = C / CG;
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    int tid = tid0, lane = tid0 & 63, n = lane & 15, j = lane >> 4;
     const long i0 = (long)blockIdx.x * items_total / gridDim.x, i1 = (long)(blockIdx.x + 1) * items_total / gridDim.x;
     int cur_tile = -1, tn = 0, ty = 0, tx = 0;
     float od[3][2][2];
-    if (tid < CG) xs[fb::ZERO * CG + tid] = 0.f;
+    if (tid < CG) xs[fb::ZERO * XP + tid] = 0.f;
 
     // dOffset of the finished tile: the four channel quarters (j) of every (pixel, tap) meet in LDS, one global atomic per value
     auto flush = [&]() {
@@ -431,6 +439,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
 
     for (long item = i0; item < i1; ++item) {
+        // the lane id goes through an opaque asm once per item: otherwise LLVM hoists ~60 registers of lane-dependent addresses out of this
+        // loop and the kernel no longer fits 3 waves per SIMD (168 VGPRs) without spilling
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; n = lane & 15; j = lane >> 4;
         const int tile = (int)(item / G), g = (int)(item - (long)tile * G);
         if (tile != cur_tile) {
             if (cur_tile >= 0) flush();
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
                     v = *reinterpret_cast<const f32x4*>(x + ((size_t)(tn * H + iy) * W + ix) * C + g * CG + q * 4);
-                *reinterpret_cast<f32x4*>(xs + pp * CG + q * 4) = v;
+                *reinterpret_cast<f32x4*>(xs + pp * XP + q * 4) = v;
             }
         }
         // B fragments: dY[pixel (2 half + p2) 16 + n][o = KS j + s]
@@ -492,6 +505,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][v], bq[p2][u][v], acc, 0, 0, 0);
                     // acc[r] = dcol[pixel][tap][ci = mt 16 + 4 j + r]
                     const int row = tap * 64 + (2 * half + p2) * 16 + n;
+#ifndef FB_NO_DOFF
                     const uint4 e = tab[row];
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(cb + (e.x & 0xFFFFu));
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(cb + (e.x >> 16));
@@ -503,11 +517,16 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     const f32x4 gw = (v1 - v0) * uh + (v3 - v2) * lh;
                     od[t][p2][0] += (acc[0] * gh[0] + acc[1] * gh[1]) + (acc[2] * gh[2] + acc[3] * gh[3]);
                     od[t][p2][1] += (acc[0] * gw[0] + acc[1] * gw[1]) + (acc[2] * gw[2] + acc[3] * gw[3]);
+                    asm volatile("" : "+v"(od[t][p2][0]), "+v"(od[t][p2][1]));     // or LLVM sinks this arithmetic (and the 20 registers of every unit
+                                                                                  // it needs) below the gather
+#endif
                     *reinterpret_cast<f32x4*>(dc + row * 16 + ((j ^ ((row >> 1) & 3)) << 2)) = acc;
+                    FB_FENCE();
                 }
             }
             __syncthreads();
             // gather: patch pixel pp sums its list; 4 lanes x 4 channels per patch pixel, longest lists first
+#ifndef FB_NO_GATHER       // experiments (wrong results): -DFB_NO_GATHER, -DFB_NO_DOFF, -DFB_NO_DXATOMIC
             {
                 const int c = tid & 3;
 #pragma unroll 1
@@ -517,23 +536,40 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         const int pp = order[task];
                         const int n0 = start[pp], n1 = start[pp + 1];
                         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                        for (int i = n0; i < n1; ++i) {
-                            const unsigned ent = inv[i];
-                            const unsigned row = ent >> 2;
-                            const float2 l = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab + row) + 8);
-                            const float wy = (ent & 2) ? l.x : 1.f - l.x, wx = (ent & 1) ? l.y : 1.f - l.y;
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(dc + row * 16 + ((c ^ ((row >> 1) & 3)) << 2));
-                            a += (wy * wx) * v;
+#pragma unroll 1
+                        for (int i = n0; i < n1; i += 4) {                 // 4 independent entries in flight (the list walk is LDS-latency bound)
+                            unsigned ent[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) ent[u] = inv[i + u < n1 ? i + u : n1 - 1];
+                            float2 l[4];
+                            f32x4 v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const unsigned row = ent[u] >> 2;
+                                l[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab + row) + 8);
+                                v[u] = *reinterpret_cast<const f32x4*>(dc + row * 16 + ((c ^ ((row >> 1) & 3)) << 2));
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float wy = (ent[u] & 2) ? l[u].x : 1.f - l[u].x, wx = (ent[u] & 1) ? l[u].y : 1.f - l[u].y;
+                                const float wgt = i + u < n1 ? wy * wx : 0.f;
+                                a += wgt * v[u];
+                            }
                         }
                         if (n1 > n0) {
                             const int r = pp / fb::PS;
                             const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + (pp - r * fb::PS);
                             float* d = dx + ((size_t)(tn * H + iy) * W + ix) * C + g * CG + mt * 16 + 4 * c;
+#ifdef FB_NO_DXATOMIC
+                            *reinterpret_cast<f32x4*>(d) = a;
+#else
                             atomicAdd(d + 0, a[0]); atomicAdd(d + 1, a[1]); atomicAdd(d + 2, a[2]); atomicAdd(d + 3, a[3]);
+#endif
                         }
                     }
                 }
             }
+#endif
             if (mt + 1 < MT) __syncthreads();
         }
     }
@@ -541,7 +577,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // Samples whose corners are not all inside the tile's patch: dcol row by plain dot products (lane = input channel of the group), per-corner
-// global atomics for dX, wave-reduced dOffset.  grid (tiles, groups); one wave per sample in turn.
+// global atomics for dX, wave-reduced dOffset.  grid (tiles, 8 group chunks); one wave per sample in turn.
 template <int CG>
 __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
                                                              const unsigned char* __restrict__ tbl, int batch, int H, int W, int C,
@@ -549,7 +585,7 @@ __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __rest
     const unsigned char* tb = tbl + (size_t)blockIdx.x * tt::BYTES;
     if (*reinterpret_cast<const unsigned*>(tb + tt::NFAR) == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.y;
+    const int G = C / CG;
     const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
     const int tile = blockIdx.x;
     const int tn = tile / (tiles_y * tiles_x), trem = tile - tn * tiles_y * tiles_x;
@@ -558,9 +594,18 @@ __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __rest
     const uint4* tab = reinterpret_cast<const uint4*>(tb + tt::TAB);
     const bool act = lane < CG;
     const int ci = act ? lane : 0;
-    for (int row = wave; row < fb::NE; row += 4) {
+    __shared__ int nlist;
+    __shared__ unsigned short list[fb::NE];
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    for (int row = tid; row < fb::NE; row += 256)
+        if (farpos[row]) list[atomicAdd(&nlist, 1)] = (unsigned short)row;
+    __syncthreads();
+    const int nl = nlist;
+    for (int g = blockIdx.y; g < G; g += gridDim.y)
+    for (int li = wave; li < nl; li += 4) {
+        const int row = list[li];
         const unsigned far = farpos[row];
-        if (!far) continue;
         const int tap = row >> 6, pixel = row & 63;
         const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);        // inside the image (far is only set for such pixels)
         const float* dyp = dy + ((size_t)(tn * H + oy) * W + ox) * C + g * CG;
@@ -676,7 +721,7 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
         hipLaunchKernelGGL(deform_bwd_pack_weight_kernel<32>, dim3((unsigned)npack), dim3(256), 0, st, weight, groups, packed_weight);
         hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, (unsigned)groups), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
                            dx, doffset);
     } else {
         static bool attr = false;
@@ -689,7 +734,7 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
         hipLaunchKernelGGL(deform_bwd_pack_weight_kernel<16>, dim3((unsigned)npack), dim3(256), 0, st, weight, groups, packed_weight);
         hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, (unsigned)groups), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
                            dx, doffset);
     }
     WT_HIP(hipGetLastError());
