@@ -253,22 +253,25 @@ __global__ __launch_bounds__(256) void deform_dw_reduce_kernel(const float* __re
 // (LDS float atomics run at ~194 cycles per wave instruction on gfx950 (tools/micro/lds_atomic_rate.hip) - a scatter into an LDS patch
 // accumulator is not an option; coalesced global float atomics cost ~5 us per 14 M, measured on det_backward.hip's gather kernel.)
 namespace tt {                             // per-tile tables in global memory (byte offsets); the first LDS_BYTES are copied to LDS as they are
-constexpr int TAB = 0;                     // uint4[576]  sampling entries, index tap * 64 + pixel
-constexpr int INV = TAB + fb::NE * 16;     // u16[2304]   (row << 2 | corner), grouped by patch pixel
-constexpr int START = INV + 2304 * 2;      // u16[200]    list of patch pixel pp = inv[start[pp] .. start[pp + 1])
+constexpr int NROW = fb::NE + 1;           // row 576 = the dummy sample (zero weights) that pads the lists to multiples of 4 entries
+constexpr int NINV = 2304 + 3 * fb::NPIX + 4;          // 2896
+constexpr int TAB = 0;                     // uint4[577]  sampling entries, index tap * 64 + pixel
+constexpr int INV = TAB + NROW * 16;       // u16[2896]   ((row * 4 + swizzle(row)) << 2 | corner), grouped by patch pixel, 4 entries (8 bytes) aligned
+constexpr int START = INV + NINV * 2;      // u16[200]    list of patch pixel pp = inv[start[pp] .. start[pp + 1])
 constexpr int ORDER = START + 400;         // u16[200]    patch pixels by descending list length
-constexpr int LDS_BYTES = ORDER + 400;     // 14 624
+constexpr int LDS_BYTES = ORDER + 400;     // 15 824
 constexpr int FARPOS = LDS_BYTES;          // u32[576]
 constexpr int NFAR = FARPOS + fb::NE * 4;  // u32
-constexpr int BYTES = NFAR + 32;           // 16 960
+constexpr int BYTES = NFAR + 32;
+static_assert(LDS_BYTES % 16 == 0 && INV % 8 == 0 && BYTES % 16 == 0, "table alignment");
 }  // namespace tt
 
 template <int CG>
 __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __restrict__ offset, int batch, int H, int W, unsigned char* __restrict__ tbl) {
-    __shared__ uint4 tab[fb::NE];
+    __shared__ uint4 tab[tt::NROW];
     __shared__ unsigned farpos[fb::NE];
     __shared__ int cnt[fb::NPIX], start[fb::NPIX + 1], cursor[fb::NPIX], hist[64], hcur[64];
-    __shared__ unsigned short inv[2304], order[fb::NPIX];
+    __shared__ unsigned short inv[tt::NINV], order[fb::NPIX];
     __shared__ int nfar;
     constexpr unsigned PB = (CG + fb::XPAD) * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,12 +314,12 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
             if (use[q]) atomicAdd(&cnt[pp[q]], 1);
     }
     __syncthreads();
-    if (wave == 0) {                           // exclusive scan of the 196 counts (4 per lane + wave scan)
+    if (wave == 0) {                           // exclusive scan of the 196 list lengths, each padded to a multiple of 4 (4 per lane + wave scan)
         int c[4], s4 = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = lane * 4 + u;
-            c[u] = idx < fb::NPIX ? cnt[idx] : 0;
+            c[u] = idx < fb::NPIX ? (cnt[idx] + 3) & ~3 : 0;
             s4 += c[u];
         }
         int inc = s4;
@@ -333,6 +336,11 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
             base += c[u];
         }
         if (lane == 63) start[fb::NPIX] = inc;
+    }
+    if (tid == 0) {                            // the dummy sample: zero weights (lh = lw = 0, corner 3), corners on the zero pixel
+        uint4 z;
+        z.x = (fb::ZERO * PB) | ((fb::ZERO * PB) << 16); z.y = z.x; z.z = 0u; z.w = 0u;
+        tab[fb::NE] = z;
     }
     for (int i = tid; i < fb::NPIX; i += 256) atomicAdd(&hist[cnt[i] < 63 ? cnt[i] : 63], 1);
     __syncthreads();
@@ -351,17 +359,19 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
         corners(tab[row], pp, use);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (use[q]) inv[atomicAdd(&cursor[pp[q]], 1)] = (unsigned short)((row << 2) | q);
+            if (use[q]) inv[atomicAdd(&cursor[pp[q]], 1)] = (unsigned short)((((row << 2) | ((row >> 1) & 3)) << 2) | q);
     }
     __syncthreads();
+    for (int i = tid; i < fb::NPIX; i += 256)
+        for (int k = cursor[i]; k < start[i + 1]; ++k) inv[k] = (unsigned short)(((fb::NE << 2) << 2) | 3);
     for (int i = tid; i < fb::NPIX; i += 256) order[atomicAdd(&hcur[cnt[i] < 63 ? cnt[i] : 63], 1)] = (unsigned short)i;
     __syncthreads();
     unsigned char* out = tbl + (size_t)tile * tt::BYTES;
-    for (int i = tid; i < fb::NE; i += 256) {
+    for (int i = tid; i < tt::NROW; i += 256) {
         reinterpret_cast<uint4*>(out + tt::TAB)[i] = tab[i];
-        reinterpret_cast<unsigned*>(out + tt::FARPOS)[i] = farpos[i];
+        if (i < fb::NE) reinterpret_cast<unsigned*>(out + tt::FARPOS)[i] = farpos[i];
     }
-    for (int i = tid; i < 2304; i += 256) reinterpret_cast<unsigned short*>(out + tt::INV)[i] = i < start[fb::NPIX] ? inv[i] : (unsigned short)0;
+    for (int i = tid; i < tt::NINV; i += 256) reinterpret_cast<unsigned short*>(out + tt::INV)[i] = i < start[fb::NPIX] ? inv[i] : (unsigned short)0;
     for (int i = tid; i < 200; i += 256) {
         reinterpret_cast<unsigned short*>(out + tt::START)[i] = (unsigned short)(i <= fb::NPIX ? start[i] : 0);
         reinterpret_cast<unsigned short*>(out + tt::ORDER)[i] = i < fb::NPIX ? order[i] : (unsigned short)0;
@@ -387,10 +397,27 @@ __global__ __launch_bounds__(256) void deform_bwd_pack_weight_kernel(const float
 // keeps the loads of the next (tap, pixel tile) unit from being hoisted over this one (register pressure: 3 waves per SIMD = 168 VGPRs)
 #define FB_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// -DFB_TIMING: cycles per phase, summed over wave 0 of every workgroup (tools only; read back with wd_deform_fb_ticks)
+#ifdef FB_TIMING
+__device__ unsigned long long fb_ticks[8];
+#define FB_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid0 == 0) atomicAdd(&fb_ticks[k], now_ - t_last); t_last = now_; } while (0)
+#else
+#define FB_T(k) do { } while (0)
+#endif
+#ifndef FB_GU
+#define FB_GU 4
+#endif
+// Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() carries a fence that would also wait for the global float
+// atomics of the gather (fire-and-forget adds into dX; nothing in the kernel reads them back) - a memory round trip per phase.
+#ifdef FB_FULL_BARRIER
+#define FB_BARRIER() __syncthreads()
+#else
+#define FB_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+#endif
 #ifndef FB_WAVES
 #define FB_WAVES __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
-template <int CG> constexpr size_t dxoff_smem_bytes() { return (size_t)(fb::NPIX + 1) * (CG + fb::XPAD) * 4 + fb::NE * 16 * 4 + tt::LDS_BYTES; }
+template <int CG> constexpr size_t dxoff_smem_bytes() { return (size_t)(fb::NPIX + 1) * (CG + fb::XPAD) * 4 + tt::NROW * 16 * 4 + tt::LDS_BYTES; }
 
 template <int CG>
 __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ wpk,
@@ -401,7 +428,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* xs = reinterpret_cast<float*>(smem);                                   // [197][XP]
     float* dc = xs + (fb::NPIX + 1) * XP;                                         // [576 rows][16 channels], 16-byte slots XOR-swizzled by row
-    unsigned char* tl = reinterpret_cast<unsigned char*>(dc + fb::NE * 16);       // the tile's tables (tt:: layout)
+    unsigned char* tl = reinterpret_cast<unsigned char*>(dc + tt::NROW * 16);     // the tile's tables (tt:: layout)
     const uint4* tab = reinterpret_cast<const uint4*>(tl + tt::TAB);
     const unsigned short* inv = reinterpret_cast<const unsigned short*>(tl + tt::INV);
     const unsigned short* start = reinterpret_cast<const unsigned short*>(tl + tt::START);
@@ -414,11 +441,15 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
     const long i0 = (long)blockIdx.x * items_total / gridDim.x, i1 = (long)(blockIdx.x + 1) * items_total / gridDim.x;
     int cur_tile = -1, tn = 0, ty = 0, tx = 0;
     float od[3][2][2];
+#ifdef FB_TIMING
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
     if (tid < CG) xs[fb::ZERO * XP + tid] = 0.f;
+    if (tid < 16) dc[fb::NE * 16 + tid] = 0.f;                 // the dummy sample's dcol row (list padding)
 
     // dOffset of the finished tile: the four channel quarters (j) of every (pixel, tap) meet in LDS, one global atomic per value
     auto flush = [&]() {
-        __syncthreads();
+        FB_BARRIER();
         float* sc = dc;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
             for (int p2 = 0; p2 < 2; ++p2)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) sc[((wave * 12) + (t * 2 + p2) * 2 + d) * 64 + lane] = od[t][p2][d];
-        __syncthreads();
+        FB_BARRIER();
         for (int i = tid; i < 64 * 18; i += 384) {
             const int pixel = i / 18, c18 = i - pixel * 18;
             const int tap = c18 >> 1, d = c18 & 1, fkh = tap / 3, t = tap - 3 * fkh;
@@ -438,6 +469,47 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
         }
     };
 
+    // prefetch registers: the NEXT item's patch (written to LDS after the item barrier) and dY fragments are requested before the last gather of
+    // the current item, the weights of the next (tap, channel half) before the MFMAs of the current one - with 3 waves per SIMD nothing else
+    // hides the L2 / HBM latency
+    constexpr int Q = CG / 4, NXP = (fb::NPIX * Q + 383) / 384;
+    f32x4 xp[NXP], bq[2][KQ], aqn[KQ];
+    auto load_item = [&](int ptile, int pg) {
+        const int ptn = ptile / (tiles_y * tiles_x), prem = ptile - ptn * tiles_y * tiles_x;
+        const int pty = prem / tiles_x, ptx = prem - pty * tiles_x;
+#pragma unroll
+        for (int u = 0; u < NXP; ++u) {
+            const int i = tid + 384 * u;
+            const int pp = i / Q, q = i - pp * Q;
+            const int r = pp / fb::PS;
+            const int iy = 8 * pty - 3 + r, ix = 8 * ptx - 3 + (pp - r * fb::PS);
+            xp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < fb::NPIX * Q && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                xp[u] = *reinterpret_cast<const f32x4*>(x + ((size_t)(ptn * H + iy) * W + ix) * C + pg * CG + q * 4);
+        }
+        // B fragments: dY[pixel (2 half + p2) 16 + n][o = KS j + s]
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            const int pixel = (2 * half + p2) * 16 + n;
+            const int oy = 8 * pty + (pixel >> 3), ox = 8 * ptx + (pixel & 7);
+            const bool in = oy < H && ox < W;
+#pragma unroll
+            for (int u = 0; u < KQ; ++u) {
+                bq[p2][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (in) bq[p2][u] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(ptn * H + oy) * W + ox) * C + pg * CG + KS * j + 4 * u);
+            }
+        }
+    };
+    auto load_w = [&](int pg, int pmt, int ptap) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wpk + ((((size_t)pg * 9 + ptap) * MT + pmt) * 64 + lane) * KS);
+#pragma unroll
+        for (int u = 0; u < KQ; ++u) aqn[u] = wp[u];
+    };
+    if (i0 < i1) {
+        const int ftile = (int)(i0 / G), fg = (int)(i0 - (long)ftile * G);
+        load_item(ftile, fg);
+        load_w(fg, 0, 3 * kh);
+    }
     for (long item = i0; item < i1; ++item) {
         // the lane id goes through an opaque asm once per item: otherwise LLVM hoists ~60 registers of lane-dependent addresses out of this
         // loop and the kernel no longer fits 3 waves per SIMD (168 VGPRs) without spilling
@@ -445,9 +517,11 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
         asm volatile("" : "+v"(tid));
         lane = tid & 63; n = lane & 15; j = lane >> 4;
         const int tile = (int)(item / G), g = (int)(item - (long)tile * G);
+        const int ntile = (int)((item + 1) / G), ng = (int)(item + 1 - (long)ntile * G);       // the next item (prefetch)
+        const bool more = item + 1 < i1;
         if (tile != cur_tile) {
             if (cur_tile >= 0) flush();
-            __syncthreads();
+            FB_BARRIER();
             const uint4* src = reinterpret_cast<const uint4*>(tbl + (size_t)tile * tt::BYTES);
             for (int i = tid; i < tt::LDS_BYTES / 16; i += 384) reinterpret_cast<uint4*>(tl)[i] = src[i];
             cur_tile = tile;
@@ -459,64 +533,60 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) od[t][p2][0] = od[t][p2][1] = 0.f;
         }
-        __syncthreads();                                   // the previous item's gather is done with xs / dc
-        {
-            constexpr int Q = CG / 4;
-            for (int i = tid; i < fb::NPIX * Q; i += 384) {
-                const int pp = i / Q, q = i - pp * Q;
-                const int r = pp / fb::PS;
-                const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + (pp - r * fb::PS);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    v = *reinterpret_cast<const f32x4*>(x + ((size_t)(tn * H + iy) * W + ix) * C + g * CG + q * 4);
-                *reinterpret_cast<f32x4*>(xs + pp * XP + q * 4) = v;
-            }
-        }
-        // B fragments: dY[pixel (2 half + p2) 16 + n][o = KS j + s]
-        f32x4 bq[2][KQ];
+        FB_BARRIER();                                   // the previous item's gather is done with xs / dc
+        FB_T(0);
 #pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2) {
-            const int pixel = (2 * half + p2) * 16 + n;
-            const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);
-            const bool in = oy < H && ox < W;
-#pragma unroll
-            for (int u = 0; u < KQ; ++u) {
-                bq[p2][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (in) bq[p2][u] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(tn * H + oy) * W + ox) * C + g * CG + KS * j + 4 * u);
-            }
+        for (int u = 0; u < NXP; ++u) {
+            const int i = tid + 384 * u;
+            const int pp = i / Q, q = i - pp * Q;
+            if (i < fb::NPIX * Q) *reinterpret_cast<f32x4*>(xs + pp * XP + q * 4) = xp[u];
         }
-        __syncthreads();
+        FB_BARRIER();
+        FB_T(1);
 #pragma unroll 1
         for (int mt = 0; mt < MT; ++mt) {
             const char* cb = reinterpret_cast<const char*>(xs + mt * 16 + 4 * j);
+            const int row0 = 3 * kh * 64 + 2 * half * 16 + n;                     // unit (t, p2): row0 + 64 t + 16 p2
+            uint4 en = tab[row0];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int tap = 3 * kh + t;
                 f32x4 aq[KQ];
-                const f32x4* wp = reinterpret_cast<const f32x4*>(wpk + ((((size_t)g * 9 + tap) * MT + mt) * 64 + lane) * KS);
 #pragma unroll
-                for (int u = 0; u < KQ; ++u) aq[u] = wp[u];
+                for (int u = 0; u < KQ; ++u) aq[u] = aqn[u];
+                if (t < 2) load_w(g, mt, tap + 1);
+                else if (mt + 1 < MT) load_w(g, mt + 1, 3 * kh);
+                else if (more) load_w(ng, 0, 3 * kh);
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
+                    const int row = row0 + 64 * t + 16 * p2;
+#ifndef FB_NO_DOFF
+                    // the unit's LDS requests first (they land under the MFMA chain), then the next unit's table entry
+                    const uint4 e = en;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(cb + (e.x & 0xFFFFu));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(cb + (e.x >> 16));
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(cb + (e.y & 0xFFFFu));
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(cb + (e.y >> 16));
+                    if (t * 2 + p2 < 5) en = tab[row0 + 64 * ((t * 2 + p2 + 1) >> 1) + 16 * ((t * 2 + p2 + 1) & 1)];
+                    asm volatile("" ::: "memory");
+#endif
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int u = 0; u < KQ; ++u)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u][v], bq[p2][u][v], acc, 0, 0, 0);
                     // acc[r] = dcol[pixel][tap][ci = mt 16 + 4 j + r]
-                    const int row = tap * 64 + (2 * half + p2) * 16 + n;
 #ifndef FB_NO_DOFF
-                    const uint4 e = tab[row];
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(cb + (e.x & 0xFFFFu));
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(cb + (e.x >> 16));
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(cb + (e.y & 0xFFFFu));
-                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(cb + (e.y >> 16));
                     const float lh = __uint_as_float(e.z), lw = __uint_as_float(e.w), uh = 1.f - lh, uw = 1.f - lw;
-                    // d val / d h = (v2 - v0)(1 - lw) + (v3 - v1) lw ;  d val / d w = (v1 - v0)(1 - lh) + (v3 - v2) lh
-                    const f32x4 gh = (v2 - v0) * uw + (v3 - v1) * lw;
-                    const f32x4 gw = (v1 - v0) * uh + (v3 - v2) * lh;
-                    od[t][p2][0] += (acc[0] * gh[0] + acc[1] * gh[1]) + (acc[2] * gh[2] + acc[3] * gh[3]);
-                    od[t][p2][1] += (acc[0] * gw[0] + acc[1] * gw[1]) + (acc[2] * gw[2] + acc[3] * gw[3]);
+                    // d val / d h = (v2 - v0)(1 - lw) + (v3 - v1) lw ;  d val / d w = (v1 - v0)(1 - lh) + (v3 - v2) lh, summed over the channels with
+                    // dcol as the weight: four dot products s_q = <dcol, v_q> (16 FMAs; VALU time adds to the MFMA time on this machine), then
+                    // the blend of their differences
+                    const float s0 = (acc[0] * v0[0] + acc[1] * v0[1]) + (acc[2] * v0[2] + acc[3] * v0[3]);
+                    const float s1 = (acc[0] * v1[0] + acc[1] * v1[1]) + (acc[2] * v1[2] + acc[3] * v1[3]);
+                    const float s2 = (acc[0] * v2[0] + acc[1] * v2[1]) + (acc[2] * v2[2] + acc[3] * v2[3]);
+                    const float s3 = (acc[0] * v3[0] + acc[1] * v3[1]) + (acc[2] * v3[2] + acc[3] * v3[3]);
+                    od[t][p2][0] += (s2 - s0) * uw + (s3 - s1) * lw;
+                    od[t][p2][1] += (s1 - s0) * uh + (s3 - s2) * lh;
                     asm volatile("" : "+v"(od[t][p2][0]), "+v"(od[t][p2][1]));     // or LLVM sinks this arithmetic (and the 20 registers of every unit
                                                                                   // it needs) below the gather
 #endif
@@ -524,36 +594,39 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
                     FB_FENCE();
                 }
             }
-            __syncthreads();
+            FB_T(2);
+            FB_BARRIER();
+            FB_T(3);
+            if (mt + 1 == MT && more) load_item(ntile, ng);        // in flight during the gather; bq is dead after the last MFMA phase
             // gather: patch pixel pp sums its list; 4 lanes x 4 channels per patch pixel, longest lists first
 #ifndef FB_NO_GATHER       // experiments (wrong results): -DFB_NO_GATHER, -DFB_NO_DOFF, -DFB_NO_DXATOMIC
             {
                 const int c = tid & 3;
 #pragma unroll 1
                 for (int round = 0; round < 3; ++round) {
-                    const int task = round * 96 + (tid >> 2);
+                    // 16 patch pixels per wave and round; the order is by descending list length: round 0 hands chunk w to wave w, round 1 chunk
+                    // 11 - w (the wave with the longest lists gets the shortest next), round 2 the last 4 (nearly empty) lists
+                    const int chunk = round == 0 ? wave : (round == 1 ? 11 - wave : 12 + wave);
+                    const int task = chunk * 16 + ((tid & 63) >> 2);
                     if (task < fb::NPIX) {
                         const int pp = order[task];
                         const int n0 = start[pp], n1 = start[pp + 1];
                         f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-                        for (int i = n0; i < n1; i += 4) {                 // 4 independent entries in flight (the list walk is LDS-latency bound)
-                            unsigned ent[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) ent[u] = inv[i + u < n1 ? i + u : n1 - 1];
+                        for (int i = n0; i < n1; i += 4) {                 // lists are padded to 4 entries (8 bytes, aligned) with zero-weight samples
+                            const uint2 e4 = *reinterpret_cast<const uint2*>(inv + i);
+                            const unsigned ent[4] = {e4.x & 0xFFFFu, e4.x >> 16, e4.y & 0xFFFFu, e4.y >> 16};
                             float2 l[4];
                             f32x4 v[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const unsigned row = ent[u] >> 2;
-                                l[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab + row) + 8);
-                                v[u] = *reinterpret_cast<const f32x4*>(dc + row * 16 + ((c ^ ((row >> 1) & 3)) << 2));
+                                l[u] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(tab) + (ent[u] & 0xFFF0u) + 8);
+                                v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(dc) + (((ent[u] >> 2) ^ c) << 4));
                             }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 const float wy = (ent[u] & 2) ? l[u].x : 1.f - l[u].x, wx = (ent[u] & 1) ? l[u].y : 1.f - l[u].y;
-                                const float wgt = i + u < n1 ? wy * wx : 0.f;
-                                a += wgt * v[u];
+                                a += (wy * wx) * v[u];
                             }
                         }
                         if (n1 > n0) {
@@ -570,7 +643,9 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
                 }
             }
 #endif
-            if (mt + 1 < MT) __syncthreads();
+            FB_T(4);
+            if (mt + 1 < MT) FB_BARRIER();
+            FB_T(5);
         }
     }
     if (cur_tile >= 0) flush();
@@ -684,6 +759,14 @@ int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, int b
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
+
+#ifdef FB_TIMING
+int wd_deform_fb_ticks(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(fb_ticks), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(fb_ticks), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 size_t wd_deform_bwd_tables_bytes(int batch, int h, int w) { return (size_t)batch * ((h + 7) / 8) * ((w + 7) / 8) * tt::BYTES; }
 
