@@ -21,10 +21,56 @@ struct LevelsW {
     float scale[kMaxLevels];
 };
 
-__global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n_levels, int C, int batch,
-                                                               const float* __restrict__ rois, int P, int min_level,
-                                                               int canonical_level, float canonical_size,
+// bilinear footprint of one ROIAlign sample coordinate (detectron2 bilinear_interpolate_gradient along one axis): rows (lo, hi), weights
+// (1 - l, l); false = the sample lies outside (-1, size) and contributes nothing
+__device__ __forceinline__ bool roi_axis_sample(float y, int size, int& lo, int& hi, float& wlo, float& whi) {
+    if (y < -1.0f || y > (float)size) return false;
+    if (y <= 0) y = 0;
+    lo = (int)y;
+    if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else hi = lo + 1;
+    whi = y - (float)lo;
+    wlo = 1.f - whi;
+    return true;
+}
+
+// The per-sample form (4 atomics per sample and channel): ROIs whose footprint exceeds the separable kernel's tables, and WD_ROI_BWD=sample.
+__device__ void roi_bwd_samples(float* __restrict__ grad, int H, int W, int C, const float* __restrict__ g0, int P, float rsh, float rsw,
+                                float bin_h, float bin_w, int gh, int gw, float count, int lane, int wave) {
+    for (int cb = wave * 64; cb < C; cb += 256) {
+        const int c = cb + lane;
+        if (c >= C) continue;
+        for (int ph = 0; ph < P; ++ph)
+            for (int pw = 0; pw < P; ++pw) {
+                const float g = g0[((size_t)ph * P + pw) * C + c] / count;
+                for (int iy = 0; iy < gh; ++iy) {
+                    const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+                    int yl, yh; float hy, ly;
+                    if (!roi_axis_sample(y, H, yl, yh, hy, ly)) continue;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+                        int xl, xh; float hx, lx;
+                        if (!roi_axis_sample(x, W, xl, xh, hx, lx)) continue;
+                        atomicAdd(&grad[((size_t)yl * W + xl) * C + c], g * hy * hx);
+                        atomicAdd(&grad[((size_t)yl * W + xh) * C + c], g * hy * lx);
+                        atomicAdd(&grad[((size_t)yh * W + xl) * C + c], g * ly * hx);
+                        atomicAdd(&grad[((size_t)yh * W + xh) * C + c], g * ly * lx);
+                    }
+                }
+            }
+    }
+}
+
+// ROIAlign backward, separable (round 4).  The gradient a ROI sends to feature pixel (y, x) is sum_{ph, pw} Wy[ph][y] Wx[pw][x] g[ph][pw] / count
+// with Wy[ph][y] = the summed bilinear weights of bin row ph's samples on row y (the out-of-range test of a sample is per axis as well): one
+// workgroup per ROI builds the two small tables in LDS, keeps the 7 x 7 bin gradients of its channels in registers, contracts the columns first
+// (T[ph] = sum_pw Wx[pw][x] g[ph][pw]) and issues ONE float atomic per footprint pixel and channel - the per-sample kernel issued 4 per sample
+// (16 - 64 samples per bin for the ROI sizes of a level): 975 us -> see DESIGN.md for a training batch of 512 ROIs.
+constexpr int RB_MAXP = 7, RB_EXT = 192;
+template <int PP>
+__global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n_levels, int C, int batch, const float* __restrict__ rois, int P,
+                                                               int min_level, int canonical_level, float canonical_size,
                                                                const float* __restrict__ gout) {
+    __shared__ float wy[RB_MAXP][RB_EXT], wx[RB_MAXP][RB_EXT];
     const int r = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* roi = rois + 5 * (size_t)r;
@@ -43,31 +89,64 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n
     const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
     const int gh = (int)ceilf(roi_h / (float)P), gw = (int)ceilf(roi_w / (float)P);
     const float count = (float)((gh * gw) > 1 ? gh * gw : 1);
+    const float* g0 = gout + (size_t)r * P * P * C;
+    // footprint: rows r0 .. r0 + nr - 1, columns c0 .. c0 + nc - 1 (every sample's two rows / columns lie inside)
+    const int r0 = max(0, min(H - 1, (int)floorf(rsh))), c0 = max(0, min(W - 1, (int)floorf(rsw)));
+    const int r1 = max(r0, min(H - 1, (int)floorf(rsh + roi_h) + 1)), c1 = max(c0, min(W - 1, (int)floorf(rsw + roi_w) + 1));
+    const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;
+    if (PP == 0 || P != PP || nr > RB_EXT || nc > RB_EXT) {
+        roi_bwd_samples(grad, H, W, C, g0, P, rsh, rsw, bin_h, bin_w, gh, gw, count, lane, wave);
+        return;
+    }
+    for (int i = threadIdx.x; i < RB_MAXP * RB_EXT; i += 256) { (&wy[0][0])[i] = 0.f; (&wx[0][0])[i] = 0.f; }
+    __syncthreads();
+    if (threadIdx.x < PP) {                        // one thread per bin row: its gh samples in turn (plain LDS adds, no two threads share a row)
+        const int ph = threadIdx.x;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
+            int lo, hi; float wl, wh;
+            if (!roi_axis_sample(y, H, lo, hi, wl, wh)) continue;
+            wy[ph][lo - r0] += wl;
+            wy[ph][hi - r0] += wh;
+        }
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + PP) {
+        const int pw = threadIdx.x - 64;
+        for (int ix = 0; ix < gw; ++ix) {
+            const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
+            int lo, hi; float wl, wh;
+            if (!roi_axis_sample(x, W, lo, hi, wl, wh)) continue;
+            wx[pw][lo - c0] += wl;
+            wx[pw][hi - c0] += wh;
+        }
+    }
+    __syncthreads();
+    const float inv_count = 1.f / count;
     for (int cb = wave * 64; cb < C; cb += 256) {
         const int c = cb + lane;
         if (c >= C) continue;
-        for (int ph = 0; ph < P; ++ph)
-            for (int pw = 0; pw < P; ++pw) {
-                const float g = gout[(((size_t)r * P + ph) * P + pw) * C + c] / count;
-                for (int iy = 0; iy < gh; ++iy) {
-                    float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
-                    for (int ix = 0; ix < gw; ++ix) {
-                        float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
-                        float yy = y;
-                        if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
-                        if (yy <= 0) yy = 0;
-                        if (x <= 0) x = 0;
-                        int yl = (int)yy, xl = (int)x, yh, xh;
-                        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
-                        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
-                        const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
-                        atomicAdd(&grad[((size_t)yl * W + xl) * C + c], g * hy * hx);
-                        atomicAdd(&grad[((size_t)yl * W + xh) * C + c], g * hy * lx);
-                        atomicAdd(&grad[((size_t)yh * W + xl) * C + c], g * ly * hx);
-                        atomicAdd(&grad[((size_t)yh * W + xh) * C + c], g * ly * lx);
-                    }
-                }
+        float g[PP > 0 ? PP : 1][PP > 0 ? PP : 1];
+#pragma unroll
+        for (int ph = 0; ph < PP; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < PP; ++pw) g[ph][pw] = g0[((size_t)ph * PP + pw) * C + c] * inv_count;
+        for (int x = 0; x < nc; ++x) {
+            float t[PP > 0 ? PP : 1];
+#pragma unroll
+            for (int ph = 0; ph < PP; ++ph) t[ph] = 0.f;
+#pragma unroll
+            for (int pw = 0; pw < PP; ++pw) {
+                const float w = wx[pw][x];
+#pragma unroll
+                for (int ph = 0; ph < PP; ++ph) t[ph] += w * g[ph][pw];
             }
+            float* __restrict__ gp = grad + ((size_t)r0 * W + c0 + x) * C + c;
+            for (int y = 0; y < nr; ++y) {
+                float v = 0.f;
+#pragma unroll
+                for (int ph = 0; ph < PP; ++ph) v += wy[ph][y] * t[ph];
+                if (v != 0.f) atomicAdd(gp + (size_t)y * W * C, v);
+            }
+        }
     }
 }
 
@@ -351,8 +430,13 @@ int wd_roi_pool_fpn_bwd_f32(float* const* grad_feats, const int32_t* heights, co
     if (n_rois <= 0) return WT_OK;
     LevelsW lv;
     for (int i = 0; i < n_levels; ++i) { lv.grad[i] = grad_feats[i]; lv.h[i] = heights[i]; lv.w[i] = widths[i]; lv.scale[i] = scales[i]; }
-    hipLaunchKernelGGL(roi_pool_fpn_bwd_kernel, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels,
-                       batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out);
+    const char* mode = getenv("WD_ROI_BWD");                 // experiments: "sample" = 4 atomics per sample (the round-1 kernel)
+    if (pooled == 7 && !(mode && strcmp(mode, "sample") == 0))
+        hipLaunchKernelGGL(roi_pool_fpn_bwd_kernel<7>, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels,
+                           batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out);
+    else
+        hipLaunchKernelGGL(roi_pool_fpn_bwd_kernel<0>, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels,
+                           batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

@@ -266,8 +266,34 @@ constexpr int BYTES = NFAR + 32;
 static_assert(LDS_BYTES % 16 == 0 && INV % 8 == 0 && BYTES % 16 == 0, "table alignment");
 }  // namespace tt
 
+// (the same launch also zeroes dX / dOffset and packs the weights: blocks >= the number of tiles, see below)
 template <int CG>
-__global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __restrict__ offset, int batch, int H, int W, unsigned char* __restrict__ tbl) {
+__global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __restrict__ offset, int batch, int H, int W, unsigned char* __restrict__ tbl,
+                                                                const float* __restrict__ weight, int C, float* __restrict__ wpk,
+                                                                float* __restrict__ dx, float* __restrict__ doff) {
+    {
+        const int ntiles = batch * ((H + 7) >> 3) * ((W + 7) >> 3);
+        if ((int)blockIdx.x >= ntiles) {
+            // auxiliary blocks: dX = 0 (the gather adds into it), and the weights (C_out, CG, 3, 3) OIHW in MFMA A-fragment order:
+            // wpk[g][tap][mt][lane = 16 j + n][s] = W[g CG + (CG / 4) j + s][mt 16 + n][tap]
+            constexpr int MT = CG / 16, KS = CG / 4;
+            const long nb = gridDim.x - ntiles, b = blockIdx.x - ntiles;
+            const long n4 = (long)batch * H * W * C / 4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (long i = b * 256 + threadIdx.x; i < n4; i += nb * 256) reinterpret_cast<f32x4*>(dx)[i] = z;
+            const long nw = (long)C * 9 * CG;
+            for (long e = b * 256 + threadIdx.x; e < nw; e += nb * 256) {
+                const int s = (int)(e % KS);
+                long q = e / KS;
+                const int lane = (int)(q & 63); q >>= 6;
+                const int mt = (int)(q % MT); q /= MT;
+                const int tap = (int)(q % 9), g = (int)(q / 9);
+                const int o = KS * (lane >> 4) + s, ci = mt * 16 + (lane & 15);
+                wpk[e] = weight[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
+            }
+            return;
+        }
+    }
     __shared__ uint4 tab[tt::NROW];
     __shared__ unsigned farpos[fb::NE];
     __shared__ int cnt[fb::NPIX], start[fb::NPIX + 1], cursor[fb::NPIX], hist[64], hcur[64];
@@ -377,21 +403,10 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
         reinterpret_cast<unsigned short*>(out + tt::ORDER)[i] = i < fb::NPIX ? order[i] : (unsigned short)0;
     }
     if (tid == 0) *reinterpret_cast<unsigned*>(out + tt::NFAR) = (unsigned)nfar;
-}
-
-// weight (C_out, CG, 3, 3) OIHW -> MFMA A-fragment order: wpk[g][tap][mt][lane = 16 j + n][s] = W[g CG + (CG / 4) j + s][mt 16 + n][tap]
-template <int CG>
-__global__ __launch_bounds__(256) void deform_bwd_pack_weight_kernel(const float* __restrict__ w, int G, float* __restrict__ wpk) {
-    constexpr int MT = CG / 16, KS = CG / 4;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= G * 9 * CG * CG) return;
-    const int s = e % KS;
-    int q = e / KS;
-    const int lane = q & 63; q >>= 6;
-    const int mt = q % MT; q /= MT;
-    const int tap = q % 9, g = q / 9;
-    const int o = KS * (lane >> 4) + s, ci = mt * 16 + (lane & 15);
-    wpk[e] = w[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
+    for (int i = tid; i < 64 * 18; i += 256) {             // dOffset of the tile = 0 (the dX / dOffset kernels add into it)
+        const int pixel = i / 18, oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);
+        if (oy < H && ox < W) doff[((size_t)(tn * H + oy) * W + ox) * 18 + (i - pixel * 18)] = 0.f;
+    }
 }
 
 // keeps the loads of the next (tap, pixel tile) unit from being hoisted over this one (register pressure: 3 waves per SIMD = 168 VGPRs)
@@ -790,9 +805,7 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
     if (const char* e = getenv("WD_DXOFF_WGS")) nwg = atoi(e);
     if (nwg > items) nwg = items;
     if (nwg < 1) nwg = 1;
-    WT_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)batch * h * w * c, st));
-    WT_HIP(hipMemsetAsync(doffset, 0, sizeof(float) * (size_t)batch * h * w * 18, st));
-    const int npack = (groups * 9 * cg * cg + 255) / 256;
+    const int naux = 4 * cus;                                // blocks that zero dX and pack the weights, in the launch that builds the tables
     if (cg == 32) {
         static bool attr = false;
         if (!attr) {
@@ -800,8 +813,8 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
                                        (int)dxoff_smem_bytes<32>()));
             attr = true;
         }
-        hipLaunchKernelGGL(deform_bwd_tables_kernel<32>, dim3((unsigned)ntiles), dim3(256), 0, st, offset, batch, h, w, tables);
-        hipLaunchKernelGGL(deform_bwd_pack_weight_kernel<32>, dim3((unsigned)npack), dim3(256), 0, st, weight, groups, packed_weight);
+        hipLaunchKernelGGL(deform_bwd_tables_kernel<32>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, h, w, tables, weight, c,
+                           packed_weight, dx, doffset);
         hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
         hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
@@ -813,8 +826,8 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
                                        (int)dxoff_smem_bytes<16>()));
             attr = true;
         }
-        hipLaunchKernelGGL(deform_bwd_tables_kernel<16>, dim3((unsigned)ntiles), dim3(256), 0, st, offset, batch, h, w, tables);
-        hipLaunchKernelGGL(deform_bwd_pack_weight_kernel<16>, dim3((unsigned)npack), dim3(256), 0, st, weight, groups, packed_weight);
+        hipLaunchKernelGGL(deform_bwd_tables_kernel<16>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, h, w, tables, weight, c,
+                           packed_weight, dx, doffset);
         hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
         hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
