@@ -146,6 +146,12 @@ int wd_gemm_nt_f32(const float* A, const float* Bt, const float* bias, const flo
  * FastRCNNConvFCHead (job.log:1149-1150).  Biased variance, like torch.nn.GroupNorm. */
 int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const float* beta, int n, int hw, int c, int groups,
                                float eps, int relu, void* stream);
+/* The same into a separate output (y == x allowed), and its backward for the training graph (round 4; torch's group_norm copies channels_last
+ * maps to NCHW and back): dx (n, HW, C), dgamma (C), dbeta (C) are overwritten; x = the forward INPUT, dy = the gradient of the (ReLU'd) output. */
+int wd_groupnorm_relu_out_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c, int groups,
+                                   float eps, int relu, void* stream);
+int wd_groupnorm_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* gamma, const float* beta, int n, int hw, int c, int groups,
+                                   float eps, int relu, float* dx, float* dgamma, float* dbeta, void* stream);
 
 /* Fused image pre-processing in front of the detector (one HBM pass): replaces TTA.pre_process
  * (detnet/nn/tta.py:179-190 ResizeTTA = F.interpolate(scale_factor, bilinear, align_corners=False); :147-156

@@ -134,6 +134,29 @@ def test_groupnorm_relu_vs_torch():
     np.testing.assert_allclose(got.cpu().double().numpy(), exp.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_groupnorm_relu_autograd_function_vs_torch():
+    """Training form of the box-head norm: forward into a second buffer + one HIP backward launch, against torch's group_norm + relu in
+    float64 (dx, dgamma, dbeta), with and without the ReLU."""
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    g = torch.Generator().manual_seed(11)
+    for (r, c, groups, relu) in ((37, 256, 32, True), (5, 128, 32, False), (64, 256, 8, True)):
+        x = torch.randn((r, c, 7, 7), generator=g) * 2 + 0.5
+        w = torch.rand(c, generator=g) + 0.5
+        b = torch.randn(c, generator=g) * 0.3
+        gy = torch.randn((r, c, 7, 7), generator=g)
+        xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+        yr = torch.nn.functional.group_norm(xr, groups, wr, br, 1e-5)
+        yr = torch.relu(yr) if relu else yr
+        yr.backward(gy.double())
+        xg, wg, bg = _cl(x).requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+        yg = ops.GroupNormReluFn.apply(xg, wg, bg, groups, 1e-5, relu)
+        yg.backward(_cl(gy))
+        np.testing.assert_allclose(yg.detach().cpu().double().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+        for name, a, e in (('dx', xg.grad, xr.grad), ('dgamma', wg.grad, wr.grad), ('dbeta', bg.grad, br.grad)):
+            err = (a.cpu().double() - e).abs().max().item() / (e.abs().max().item() + 1e-12)
+            assert err < 1e-4, (name, r, c, groups, err)
+
+
 def test_deform_conv_backward_vs_autograd_reference():
     """dX, dOffset, dW of the HIP backward (im2col / GEMMs / col2im) vs torch autograd through the CPU restatement
     (grid_sample based) in float64."""

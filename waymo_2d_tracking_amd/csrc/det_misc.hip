@@ -20,10 +20,11 @@ __global__ __launch_bounds__(256) void bias_relu_kernel(float4* __restrict__ y, 
 // One workgroup per ROI, one thread per channel: the HW (<= 64) values of a channel stay in registers, group
 // statistics are reduced across the CPG lanes of the group with xor-shuffles (two-pass mean / variance).
 template <int CPG>
-__global__ __launch_bounds__(256) void groupnorm_relu_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* x, float* y, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int HW, int C, float eps,
                                                              int relu) {
-    float* base = x + (size_t)blockIdx.x * HW * C;
+    const float* base = x + (size_t)blockIdx.x * HW * C;
+    float* obase = y + (size_t)blockIdx.x * HW * C;          // y == x: in place (a thread only rewrites what it read)
     for (int c = threadIdx.x; c < C; c += 256) {            // C is a multiple of CPG; 256 % CPG == 0
         float v[64];
         float s = 0.f;
@@ -48,11 +49,65 @@ __global__ __launch_bounds__(256) void groupnorm_relu_kernel(float* __restrict__
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
             if (i < HW) {
-                float y = v[i] * g + b;
-                if (relu) y = fmaxf(y, 0.f);
-                base[(size_t)i * C + c] = y;
+                float o = v[i] * g + b;
+                if (relu) o = fmaxf(o, 0.f);
+                obase[(size_t)i * C + c] = o;
             }
         }
+    }
+}
+
+// Backward of GroupNorm + ReLU on the same layout (training graph, round 4: torch's group_norm copied every channels_last box-head map to
+// NCHW and back - 42 x 26 MB per step).  Same mapping: the HW values of a channel (input x and incoming gradient) stay in registers, the
+// statistics are recomputed, and with g = dy * (y > 0), xh = (x - mean) * rstd, m = HW * CPG:
+//   dbeta[c] += sum_i g, dgamma[c] += sum_i g xh (one float atomic per channel and ROI)
+//   dx = rstd * (gamma g - A / m - xh B / m),  A = sum over the group of gamma g, B = sum over the group of gamma g xh
+template <int CPG>
+__global__ __launch_bounds__(256) void groupnorm_relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int HW, int C, float eps, int relu,
+                                                                 float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const size_t off = (size_t)blockIdx.x * HW * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v[64], g[64];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            v[i] = (i < HW) ? x[off + (size_t)i * C + c] : 0.f;
+            g[i] = (i < HW) ? dy[off + (size_t)i * C + c] : 0.f;
+            s += v[i];
+        }
+#pragma unroll
+        for (int o = 1; o < CPG; o <<= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s / (float)(HW * CPG);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float d = (i < HW) ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+#pragma unroll
+        for (int o = 1; o < CPG; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q / (float)(HW * CPG) + eps);
+        const float ga = gamma[c], be = beta[c];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float xh = (v[i] - mean) * rstd;
+            if (relu && !(xh * ga + be > 0.f)) g[i] = 0.f;
+            v[i] = xh;
+            sg += g[i];
+            sgx += g[i] * xh;
+        }
+        atomicAdd(dbeta + c, sg);
+        atomicAdd(dgamma + c, sgx);
+        float A = ga * sg, B = ga * sgx;
+#pragma unroll
+        for (int o = 1; o < CPG; o <<= 1) { A += __shfl_xor(A, o, 64); B += __shfl_xor(B, o, 64); }
+        const float im = 1.f / (float)(HW * CPG);
+        A *= im; B *= im;
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            if (i < HW) dx[off + (size_t)i * C + c] = rstd * (ga * g[i] - A - v[i] * B);
     }
 }
 
@@ -90,8 +145,44 @@ __global__ __launch_bounds__(256) void tap_shift_add_kernel(const float* __restr
 
 }  // namespace
 
+extern "C" int wd_groupnorm_relu_out_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c, int groups,
+                                              float eps, int relu, void* stream);
+
 extern "C" int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const float* beta, int n, int hw, int c, int groups,
                                           float eps, int relu, void* stream) {
+    return wd_groupnorm_relu_out_nhwc_f32(x, x, gamma, beta, n, hw, c, groups, eps, relu, stream);
+}
+
+static int gn_check(const char* who, int hw, int c, int groups) {
+    const int cpg = groups > 0 ? c / groups : 0;
+    if (groups <= 0 || c % groups || hw < 1 || hw > 64 || c % 64 || (cpg != 4 && cpg != 8 && cpg != 16 && cpg != 32)) {
+        wt::set_error("%s: need hw <= 64, C %% 64 == 0, 4 / 8 / 16 / 32 channels per group (hw=%d C=%d groups=%d)", who, hw, c, groups);
+        return WT_ERR_INVALID;
+    }
+    return WT_OK;
+}
+
+extern "C" int wd_groupnorm_relu_bwd_nhwc_f32(const float* x, const float* dy, const float* gamma, const float* beta, int n, int hw, int c, int groups,
+                                              float eps, int relu, float* dx, float* dgamma, float* dbeta, void* stream) {
+    WT_TRY(wt::ensure_device());
+    WT_TRY(gn_check("wd_groupnorm_relu_bwd_nhwc_f32", hw, c, groups));
+    hipStream_t st = (hipStream_t)stream;
+    WT_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * c, st));
+    WT_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * c, st));
+    if (n <= 0) return WT_OK;
+    const int cpg = c / groups;
+#define WD_GNB(CPG) hipLaunchKernelGGL(groupnorm_relu_bwd_kernel<CPG>, dim3((unsigned)n), dim3(256), 0, st, x, dy, gamma, beta, hw, c, eps, relu, dx, dgamma, dbeta)
+    if (cpg == 8) WD_GNB(8);
+    else if (cpg == 4) WD_GNB(4);
+    else if (cpg == 16) WD_GNB(16);
+    else WD_GNB(32);
+#undef WD_GNB
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+extern "C" int wd_groupnorm_relu_out_nhwc_f32(const float* x, float* y, const float* gamma, const float* beta, int n, int hw, int c, int groups,
+                                              float eps, int relu, void* stream) {
     WT_TRY(wt::ensure_device());
     if (n <= 0) return WT_OK;
     const int cpg = groups > 0 ? c / groups : 0;
@@ -99,7 +190,7 @@ extern "C" int wd_groupnorm_relu_nhwc_f32(float* x, const float* gamma, const fl
         wt::set_error("wd_groupnorm_relu_nhwc_f32: need hw <= 64, C %% 64 == 0, C %% groups == 0 (hw=%d C=%d groups=%d)", hw, c, groups);
         return WT_ERR_INVALID;
     }
-#define WD_GN(CPG) hipLaunchKernelGGL(groupnorm_relu_kernel<CPG>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, hw, c, eps, relu)
+#define WD_GN(CPG) hipLaunchKernelGGL(groupnorm_relu_kernel<CPG>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, hw, c, eps, relu)
     if (cpg == 8) WD_GN(8);
     else if (cpg == 4) WD_GN(4);
     else if (cpg == 16) WD_GN(16);

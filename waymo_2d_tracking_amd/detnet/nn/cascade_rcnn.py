@@ -356,7 +356,10 @@ class BoxHead(nn.Module):
         for conv, norm in zip(self.convs, self.norms):
             x = conv(x)
             if train:
-                x = F.relu(norm(x))
+                if FUSED_TRAINING_EPILOGUES and x.shape[2] * x.shape[3] <= 64 and x.shape[0] > 0:
+                    x = ops.GroupNormReluFn.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True)
+                else:
+                    x = F.relu(norm(x))
                 continue
             if not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)

@@ -238,6 +238,37 @@ def groupnorm_relu_(x, weight, bias, groups, eps=1e-5, relu=True):
     return x
 
 
+class GroupNormReluFn(torch.autograd.Function):
+    """y = relu(GroupNorm(x)) on (R,C,H,W) channels_last maps with H*W <= 64 (training graph of the box heads): the inference kernel writing to
+    a second buffer, and one HIP backward launch (wd_groupnorm_relu_bwd_nhwc_f32) that recomputes the statistics from the saved input."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu):
+        x = _nhwc(x)
+        r, c, h, w = x.shape
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().wd_groupnorm_relu_out_nhwc_f32(_p(x), _p(y), _p(weight), _p(bias), C.c_int(r), C.c_int(h * w), C.c_int(c),
+                                                             C.c_int(groups), C.c_float(eps), C.c_int(1 if relu else 0), _stream()),
+                   'wd_groupnorm_relu_out_nhwc_f32')
+        ctx.save_for_backward(x, weight, bias)
+        ctx.cfg = (groups, eps, bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        groups, eps, relu = ctx.cfg
+        dy = _nhwc(dy)
+        r, c, h, w = x.shape
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        db = torch.empty(c, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().wd_groupnorm_relu_bwd_nhwc_f32(_p(x), _p(dy), _p(weight), _p(bias), C.c_int(r), C.c_int(h * w), C.c_int(c),
+                                                             C.c_int(groups), C.c_float(eps), C.c_int(1 if relu else 0), _p(dx), _p(dg), _p(db),
+                                                             _stream()), 'wd_groupnorm_relu_bwd_nhwc_f32')
+        return dx, dg, db, None, None, None
+
+
 def tap_gemm_weight(weight, align=16):
     """(n_out, C, 3, 3) conv weight -> (ld, C) GEMM operand with row tap*n_out + n (tap = kh*3 + kw), zero rows up to
     ld = 9*n_out rounded up to `align` (keeps the rows of the GEMM result 16-byte aligned)."""
