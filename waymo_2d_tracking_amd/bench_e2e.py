@@ -640,19 +640,32 @@ def run_train(args, world, rank, timed_steps):
     # roofline of the dominant hand-written BACKWARD kernel: deformable col2im (dx as a gather over the inverted sampling table +
     # doffset), HBM-bound: algorithmic bytes per launch / mean launch duration of the most expensive shape
     by = {}
-    for tag, nbytes, e0, e1 in log:
-        if tag.startswith('deform_col2im'):
-            d = by.setdefault(tag, [0, 0.0, nbytes])
+    for tag, work, e0, e1 in log:
+        if tag.startswith('deform_col2im') or tag.startswith('deform_dxoff'):
+            d = by.setdefault(tag, [0, 0.0, work])
             d[0] += 1
             d[1] += e0.elapsed_time(e1)
     roofline = None
     if by:
+        # round 4: the stride-1 layers of res3 / res4 run the fused backward (dcol = dY W on the f32 MFMAs inside the kernel, never in HBM): its
+        # roof is the MFMA peak and the work logged is algorithmic flops; the remaining layers (stride 2, res5) keep the HBM-bound col2im form
         tag = max(by, key=lambda k: by[k][1])
-        cnt, ms, nbytes = by[tag]
-        ach = nbytes / (ms / cnt * 1e-3) / 1e9
-        roofline = dict(bound='hbm', kernel=tag, achieved=ach, peak=8000.0, unit='GB/s', frac=ach / 8000.0, traffic=None, launches=cnt,
-                        avg_us=ms / cnt * 1e3, bytes_per_launch=nbytes,
-                        all_shapes={k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, gbs=v[2] / (v[1] / v[0] * 1e-3) / 1e9) for k, v in by.items()})
+        cnt, ms, work = by[tag]
+
+        def rate(k, v):
+            per_s = v[2] / (v[1] / v[0] * 1e-3)
+            return dict(launches=v[0], avg_us=v[1] / v[0] * 1e3, **({'tflops': per_s / 1e12} if k.startswith('deform_dxoff') else {'gbs': per_s / 1e9}))
+        if tag.startswith('deform_dxoff'):
+            ach = work / (ms / cnt * 1e-3) / 1e12
+            roofline = dict(bound='mfma', kernel=tag, achieved=ach, peak=157.3, unit='TFLOP/s', frac=ach / 157.3, traffic=None, launches=cnt,
+                            avg_us=ms / cnt * 1e3, flops_per_launch=work,
+                            note='avg_us covers the four launches of the fused dX / dOffset path (tables, main kernel, far samples); only the '
+                                 'dcol GEMM flops are counted - the gather and the dOffset dot products are VALU work on the same SIMDs',
+                            all_shapes={k: rate(k, v) for k, v in by.items()})
+        else:
+            ach = work / (ms / cnt * 1e-3) / 1e9
+            roofline = dict(bound='hbm', kernel=tag, achieved=ach, peak=8000.0, unit='GB/s', frac=ach / 8000.0, traffic=None, launches=cnt,
+                            avg_us=ms / cnt * 1e3, bytes_per_launch=work, all_shapes={k: rate(k, v) for k, v in by.items()})
     res = dict(value=world * steps / dt, unit='images/s', ms_per_step=1e3 * dt / steps, dtype='f32',
                workload='Cascade R-CNN X152-32x8d-FPN dconv training step (fwd+bwd+SGD), 886x1280 crop, batch 1/GPU, '
                         '30 synthetic gt boxes, FREEZE_AT 2, FrozenBN, %s' % ('DDP x%d over RCCL' % world if world > 1 else 'single GPU'),

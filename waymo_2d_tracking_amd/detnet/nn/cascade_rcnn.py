@@ -389,6 +389,11 @@ class CascadeRCNN(nn.Module):
         self.register_buffer('pixel_mean', torch.tensor(PIXEL_MEAN).view(1, 3, 1, 1))
         self.register_buffer('pixel_std', torch.tensor(PIXEL_STD).view(1, 3, 1, 1))
         self.to(memory_format=torch.channels_last)
+        # the grouped / deformable 3x3 weights are consumed by the HIP kernels only, which read OIHW: keep them contiguous (channels_last strides
+        # cost a 1.2 MB copy per layer in forward and again in backward)
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                m.conv2_weight.data = m.conv2_weight.data.contiguous()
 
     def preprocess(self, image_bgr):
         """(1,3,H,W) float 0..255 BGR -> normalised, zero-padded to a multiple of 32 (size_divisibility), NHWC."""

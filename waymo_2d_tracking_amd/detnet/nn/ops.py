@@ -591,8 +591,17 @@ def deform_dxoff(x, offset, dy_nhwc, weight, groups):
     packed = torch.empty(weight.numel(), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     doff = torch.empty_like(offset, memory_format=torch.channels_last)
+    log = EVENT_LOG
+    if log is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L.wd_deform_dxoff_f32(_p(x), _p(offset), _p(dy_nhwc), _p(weight.contiguous()), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
                                      C.c_int(groups), _p(tables), _p(packed), _p(dx), _p(doff), _stream()), 'wd_deform_dxoff_f32')
+    if log is not None:
+        e1.record()
+        # algorithmic flops: dcol = dY W per group on the f32 MFMAs (the gather and the dOffset dot products are VALU work on top)
+        log.append(('deform_dxoff (tables + dX gather + dOffset + far samples): C=%d %dx%d' % (c, h, w), 2.0 * n * h * w * 9 * (c // groups) * c, e0, e1))
     return dx, doff
 
 
