@@ -194,7 +194,7 @@ int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset,
                          int stride, int pad, float* dx, float* doffset, void* stream);
 /* Fused form of the same backward for stride 1 / pad 1 / C_out = C_in / 16 or 32 channels per group (every stride-1 DeformConv of res3 and
  * res4; round 4): the column slab is never written to HBM.
- *   wd_deform_dw_f32 : dw (groups, C/groups [o], 9 [tap], C/groups [ci]) = sum over output pixels of dY[p][o] * col[p][tap][ci]
+ *   wd_deform_dw_f32 : dw (C, C/groups, 3, 3) OIHW, the layout of the weight = sum over output pixels of dY[p][o] * col[p][tap][ci]
  *                      (the im2col + dW GEMM pair; dw is overwritten).  dy (N,H,W,C) NHWC. */
 /*   wd_deform_dxoff_f32 : dx (N,H,W,C) and doffset (N,H,W,18), both overwritten (the dcol GEMM + col2im pair).  weight = the (C, C/groups,
  *                      3, 3) OIHW tensor; tables (wd_deform_bwd_tables_bytes) and packed_weight (C * 9 * C/groups floats) are scratch. */

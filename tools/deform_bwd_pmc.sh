@@ -10,12 +10,12 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/dbwpmc -- python3 $R/tools/deform_fused_bwd_bench.py > /tmp/dbwpmc.log 2>&1
   f=$(find /tmp/dbwpmc -name "*counter_collection.csv" | head -1)
   python3 - "$f" >> $OUT <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    n = r['Kernel_Name']
-    if 'deform_d' in n:
-        acc[n.split('(')[0][-28:]][r['Counter_Name']].append(float(r['Counter_Value']))
+    m = re.search(r'(deform_d\w+<\d+>)', r['Kernel_Name'])
+    if m:
+        acc[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in sorted(acc.items()):
     print('  %-30s' % k, ' '.join('%s=%.4g' % (c, sum(v) / len(v)) for c, v in sorted(d.items())), 'n=%d' % len(next(iter(d.values()))))
 PY

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(192) void deform_dw_kernel(const float* __restrict_
                 for (int r = 0; r < 4; ++r) pw[(((t * MT + mt) * MT + nt) * 4 + r) * 64] = acc[t][mt][nt][r];
 }
 
-// dW[g][o][tap][ci] = sum over slices of the partials.  D[i = 4 j + r][n] of tile (mt, nt) = dW[o = MT i + mt][tap][ci = MT n + nt].
+// dW[g CG + o][ci][tap] (OIHW) = sum over slices of the partials.  D[i = 4 j + r][n] of tile (mt, nt) = dW[o = MT i + mt][tap][ci = MT n + nt].
 template <int CG>
 __global__ __launch_bounds__(256) void deform_dw_reduce_kernel(const float* __restrict__ part, int G, int slices, float* __restrict__ dw) {
     constexpr int MT = CG / 16, PER = 9 * CG * CG;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void deform_dw_reduce_kernel(const float* __re
     const int mt = q % MT; q /= MT;
     const int t = q % 3, wave = q / 3;
     const int o = MT * (4 * (lane >> 4) + r) + mt, ci = MT * (lane & 15) + nt;
-    dw[(((size_t)g * CG + o) * 9 + 3 * wave + t) * CG + ci] = s;
+    dw[(((size_t)g * CG + o) * CG + ci) * 9 + 3 * wave + t] = s;               // OIHW, the layout of the weight itself
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

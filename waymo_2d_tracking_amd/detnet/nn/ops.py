@@ -567,12 +567,12 @@ def fused_deform_backward_supported(c, cout, groups, stride, pad):
 
 
 def deform_dw(x, offset, dy_nhwc, groups):
-    """dW as (groups, C/groups [o], 9, C/groups [ci]) from x, offset and dy (N,H,W,C contiguous) in one launch: the columns are blended
-    per tile in registers and consumed by the MFMAs directly (wd_deform_dw_f32)."""
+    """dW (C, C/groups, 3, 3) from x, offset and dy (N,H,W,C contiguous): the columns are blended per tile in registers and consumed by the
+    MFMAs directly, a second launch sums the workgroups' partial sums into the weight's own layout (wd_deform_dw_f32)."""
     x = _nhwc(x); offset = _nhwc(offset)
     n, c, h, w = x.shape
     cg = c // groups
-    dw = torch.empty((groups, cg, 9, cg), dtype=torch.float32, device=x.device)
+    dw = torch.empty((c, cg, 3, 3), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     scratch = torch.empty(L.wd_deform_dw_scratch_floats(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups)), dtype=torch.float32,
                           device=x.device)
@@ -639,11 +639,11 @@ class DeformConvFn(torch.autograd.Function):
         fused = fused_deform_backward_supported(x.shape[1], cout, groups, stride, pad)
         if ctx.needs_input_grad[2]:
             if fused:
-                dwg = deform_dw(x, offset, dyn.contiguous(), groups)
+                dw = deform_dw(x, offset, dyn.contiguous(), groups)
             else:
                 col = deform_im2col(x, offset, stride, pad, groups).view(groups, p, 9 * cg)
                 dwg = torch.bmm(dyg.transpose(1, 2), col)                       # (G, cog, 9*cg): [g][o][k][i]
-            dw = dwg.view(groups, cog, 9, cg).permute(0, 1, 3, 2).reshape(cout, cg, 3, 3)
+                dw = dwg.view(groups, cog, 9, cg).permute(0, 1, 3, 2).reshape(cout, cg, 3, 3)
         if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and fused and FUSED_DEFORM_DXOFF:
             dx, doff = deform_dxoff(x, offset, dyn.contiguous(), weight, groups)
         elif ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
