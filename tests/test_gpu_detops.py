@@ -157,11 +157,13 @@ def test_groupnorm_relu_autograd_function_vs_torch():
             assert err < 1e-4, (name, r, c, groups, err)
 
 
-def test_deform_conv_backward_vs_autograd_reference():
+@pytest.mark.parametrize('fold_epilogue', ['0', '1'])
+def test_deform_conv_backward_vs_autograd_reference(fold_epilogue, monkeypatch):
     """dX, dOffset, dW of the HIP backward (im2col / GEMMs / col2im) vs torch autograd through the CPU restatement
     (grid_sample based) in float64."""
     from oracle import detector_ref as R
     from waymo_2d_tracking_amd.detnet.nn import ops
+    monkeypatch.setenv('WD_FUSED_DEFORM_EPILOGUE', fold_epilogue)      # 1: the fused kernels mask / scale dY themselves (off by default)
     g = torch.Generator().manual_seed(21)
     # stride 1: LDS-accumulating dx kernel (small offsets stay in the patch, the 4.0-scaled case also takes its global
     # path); stride 2: one global atomic per corner value
@@ -181,6 +183,20 @@ def test_deform_conv_backward_vs_autograd_reference():
             a, b = a.cpu().double(), b
             err = (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
             assert err < 2e-4, (name, C, stride, err)
+        # the block's fused epilogue y = relu(conv * scale + bias): its backward rides on the dY loads of the fused kernels (stride 1) or is one
+        # masking pass in front of the column-slab form (stride 2)
+        scale = torch.rand(C, generator=g) + 0.5
+        bias = torch.randn(C, generator=g) * 0.2
+        xr, orf, wr = x.double().requires_grad_(), offset.double().requires_grad_(), weight.double().requires_grad_()
+        yr = torch.relu(R.deform_conv3x3(xr, orf, wr, 32, stride, 1) * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1))
+        yr.backward(gy.double())
+        xg = _cl(x).requires_grad_(); og = _cl(offset).requires_grad_(); wg = weight.cuda().requires_grad_()
+        yg = ops.DeformConvFn.apply(xg, og, wg, 32, stride, 1, scale.cuda(), bias.cuda(), True)
+        yg.backward(_cl(gy))
+        assert (yg.detach().cpu().double() - yr.detach()).abs().max().item() < 2e-4 * yr.abs().max().item()
+        for name, a, b in (('dx', xg.grad, xr.grad), ('doffset', og.grad, orf.grad), ('dw', wg.grad, wr.grad)):
+            err = (a.cpu().double() - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+            assert err < 2e-4, ('fused epilogue', name, C, stride, err)
 
 
 def test_roi_pool_backward_vs_autograd_reference():

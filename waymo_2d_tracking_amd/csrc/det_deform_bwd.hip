@@ -66,6 +66,11 @@ template <int V> struct fb_vec { using type = float; };
 template <> struct fb_vec<2> { using type = f32x2; };
 
 template <int V> __device__ __forceinline__ typename fb_vec<V>::type fb_zero() { typename fb_vec<V>::type z = {}; return z; }
+__device__ __forceinline__ float fb_mask(float g, float y) { return y > 0.f ? g : 0.f; }
+__device__ __forceinline__ f32x2 fb_mask(f32x2 g, f32x2 y) { return f32x2{y[0] > 0.f ? g[0] : 0.f, y[1] > 0.f ? g[1] : 0.f}; }
+__device__ __forceinline__ f32x4 fb_mask(f32x4 g, f32x4 y) {
+    return f32x4{y[0] > 0.f ? g[0] : 0.f, y[1] > 0.f ? g[1] : 0.f, y[2] > 0.f ? g[2] : 0.f, y[3] > 0.f ? g[3] : 0.f};
+}
 __device__ __forceinline__ float fb_at(float v, int) { return v; }
 __device__ __forceinline__ float fb_at(f32x2 v, int i) { return v[i]; }
 
@@ -131,6 +136,7 @@ __device__ __forceinline__ typename fb_vec<V>::type fb_sample_far(const uint4 e,
 
 template <int CG>
 __global__ __launch_bounds__(192) void deform_dw_kernel(const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ dy,
+                                                        const float* __restrict__ yact, const float* __restrict__ scale,
                                                         int batch, int H, int W, int C, int slices, float* __restrict__ part) {
     constexpr int MT = CG / 16;                  // 16-wide tiles along o and along ci; a lane holds MT consecutive channels (o = MT i + mt)
     using vec = typename fb_vec<MT>::type;
@@ -150,6 +156,9 @@ __global__ __launch_bounds__(192) void deform_dw_kernel(const float* __restrict_
 #pragma unroll
             for (int b = 0; b < MT; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < CG) xs[fb::ZERO * CG + tid] = 0.f;
+    // backward of the block's fused epilogue on the fly: dY_eff = dY * (y > 0) * scale[channel] (yact / scale may be null)
+    vec sc = fb_zero<MT>();
+    if (scale) sc = *reinterpret_cast<const vec*>(scale + g * CG + MT * n);
     for (int tile = slice; tile < ntiles; tile += slices) {
         const int tn = tile / (tiles_y * tiles_x), trem = tile - tn * tiles_y * tiles_x;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -166,7 +175,12 @@ __global__ __launch_bounds__(192) void deform_dw_kernel(const float* __restrict_
         for (int s = 0; s < 16; ++s) {
             const int oy = 8 * ty + (s >> 1), ox = 8 * tx + 4 * (s & 1) + j;
             a[s] = fb_zero<MT>();
-            if (oy < H && ox < W) a[s] = *reinterpret_cast<const vec*>(dy + ((size_t)(tn * H + oy) * W + ox) * C + g * CG + MT * n);
+            if (oy < H && ox < W) {
+                const size_t at = ((size_t)(tn * H + oy) * W + ox) * C + g * CG + MT * n;
+                a[s] = *reinterpret_cast<const vec*>(dy + at);
+                if (yact) a[s] = fb_mask(a[s], *reinterpret_cast<const vec*>(yact + at));
+                if (scale) a[s] = a[s] * sc;
+            }
         }
         __syncthreads();
         const char* xl = reinterpret_cast<const char*>(xs + MT * n);
@@ -435,7 +449,8 @@ __device__ unsigned long long fb_ticks[8];
 template <int CG> constexpr size_t dxoff_smem_bytes() { return (size_t)(fb::NPIX + 1) * (CG + fb::XPAD) * 4 + tt::NROW * 16 * 4 + tt::LDS_BYTES; }
 
 template <int CG>
-__global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ wpk,
+__global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    const float* __restrict__ yact, const float* __restrict__ scale, const float* __restrict__ wpk,
                                                            const unsigned char* __restrict__ tbl, int batch, int H, int W, int C, int items_total,
                                                            float* __restrict__ dx, float* __restrict__ doff) {
     constexpr int MT = CG / 16, KS = CG / 4, KQ = KS / 4;       // k-steps of 4 output channels; float4s per operand fragment
@@ -511,7 +526,13 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
 #pragma unroll
             for (int u = 0; u < KQ; ++u) {
                 bq[p2][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (in) bq[p2][u] = *reinterpret_cast<const f32x4*>(dy + ((size_t)(ptn * H + oy) * W + ox) * C + pg * CG + KS * j + 4 * u);
+                if (in) {
+                    const size_t at = ((size_t)(ptn * H + oy) * W + ox) * C + pg * CG + KS * j + 4 * u;
+                    bq[p2][u] = *reinterpret_cast<const f32x4*>(dy + at);
+                    // backward of the block's fused epilogue on the fly: dY_eff = dY * (y > 0) * scale[channel]
+                    if (yact) bq[p2][u] = fb_mask(bq[p2][u], *reinterpret_cast<const f32x4*>(yact + at));
+                    if (scale) bq[p2][u] = bq[p2][u] * *reinterpret_cast<const f32x4*>(scale + pg * CG + KS * j + 4 * u);
+                }
             }
         }
     };
@@ -669,7 +690,8 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
 // Samples whose corners are not all inside the tile's patch: dcol row by plain dot products (lane = input channel of the group), per-corner
 // global atomics for dX, wave-reduced dOffset.  grid (tiles, 8 group chunks); one wave per sample in turn.
 template <int CG>
-__global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
+                                                             const float* __restrict__ scale, const float* __restrict__ w,
                                                              const unsigned char* __restrict__ tbl, int batch, int H, int W, int C,
                                                              float* __restrict__ dx, float* __restrict__ doff) {
     const unsigned char* tb = tbl + (size_t)blockIdx.x * tt::BYTES;
@@ -698,9 +720,14 @@ __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __rest
         const unsigned far = farpos[row];
         const int tap = row >> 6, pixel = row & 63;
         const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);        // inside the image (far is only set for such pixels)
-        const float* dyp = dy + ((size_t)(tn * H + oy) * W + ox) * C + g * CG;
+        const size_t dat = ((size_t)(tn * H + oy) * W + ox) * C + g * CG;
         float gcol = 0.f;
-        for (int o = 0; o < CG; ++o) gcol += dyp[o] * w[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
+        for (int o = 0; o < CG; ++o) {
+            float d = dy[dat + o];
+            if (yact && !(yact[dat + o] > 0.f)) d = 0.f;
+            if (scale) d *= scale[g * CG + o];
+            gcol += d * w[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
+        }
         if (!act) gcol = 0.f;
         const uint4 e = tab[row];
         const float lh = __uint_as_float(e.z), lw = __uint_as_float(e.w), uh = 1.f - lh, uw = 1.f - lw;
@@ -756,8 +783,8 @@ size_t wd_deform_dw_scratch_floats(int batch, int h, int w, int c, int groups) {
     return (size_t)fused_dw_slices(batch, h, w, groups, cg) * groups * 9 * cg * cg;
 }
 
-int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, int batch, int h, int w, int c, int groups, float* scratch, float* dw,
-                     void* stream) {
+int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, const float* y_act, const float* scale, int batch, int h, int w, int c,
+                     int groups, float* scratch, float* dw, void* stream) {
     WT_TRY(wt::ensure_device());
     WT_TRY(check_fused("wd_deform_dw_f32", c, groups, h, w));
     const int cg = c / groups;
@@ -765,10 +792,10 @@ int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, int b
     const int slices = fused_dw_slices(batch, h, w, groups, cg);
     const int nred = (groups * 9 * cg * cg + 255) / 256;
     if (cg == 32) {
-        hipLaunchKernelGGL(deform_dw_kernel<32>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, batch, h, w, c, slices, scratch);
+        hipLaunchKernelGGL(deform_dw_kernel<32>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, y_act, scale, batch, h, w, c, slices, scratch);
         hipLaunchKernelGGL(deform_dw_reduce_kernel<32>, dim3((unsigned)nred), dim3(256), 0, st, scratch, groups, slices, dw);
     } else {
-        hipLaunchKernelGGL(deform_dw_kernel<16>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, batch, h, w, c, slices, scratch);
+        hipLaunchKernelGGL(deform_dw_kernel<16>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, y_act, scale, batch, h, w, c, slices, scratch);
         hipLaunchKernelGGL(deform_dw_reduce_kernel<16>, dim3((unsigned)nred), dim3(256), 0, st, scratch, groups, slices, dw);
     }
     WT_HIP(hipGetLastError());
@@ -785,8 +812,8 @@ int wd_deform_fb_ticks(unsigned long long* out8, int reset) {
 
 size_t wd_deform_bwd_tables_bytes(int batch, int h, int w) { return (size_t)batch * ((h + 7) / 8) * ((w + 7) / 8) * tt::BYTES; }
 
-int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, const float* weight, int batch, int h, int w, int c, int groups,
-                        unsigned char* tables, float* packed_weight, float* dx, float* doffset, void* stream) {
+int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, const float* y_act, const float* scale, const float* weight, int batch,
+                        int h, int w, int c, int groups, unsigned char* tables, float* packed_weight, float* dx, float* doffset, void* stream) {
     WT_TRY(wt::ensure_device());
     WT_TRY(check_fused("wd_deform_dxoff_f32", c, groups, h, w));
     const int cg = c / groups;
@@ -815,9 +842,9 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
         }
         hipLaunchKernelGGL(deform_bwd_tables_kernel<32>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, h, w, tables, weight, c,
                            packed_weight, dx, doffset);
-        hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, packed_weight, tables, batch, h,
+        hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, y_act, scale, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, y_act, scale, weight, tables, batch, h, w, c,
                            dx, doffset);
     } else {
         static bool attr = false;
@@ -828,9 +855,9 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
         }
         hipLaunchKernelGGL(deform_bwd_tables_kernel<16>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, h, w, tables, weight, c,
                            packed_weight, dx, doffset);
-        hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, packed_weight, tables, batch, h,
+        hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, y_act, scale, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, y_act, scale, weight, tables, batch, h, w, c,
                            dx, doffset);
     }
     WT_HIP(hipGetLastError());

@@ -566,7 +566,7 @@ def fused_deform_backward_supported(c, cout, groups, stride, pad):
     return FUSED_DEFORM_BACKWARD and stride == 1 and pad == 1 and c == cout and c % groups == 0 and c // groups in (16, 32)
 
 
-def deform_dw(x, offset, dy_nhwc, groups):
+def deform_dw(x, offset, dy_nhwc, groups, y_act=None, scale=None):
     """dW (C, C/groups, 3, 3) from x, offset and dy (N,H,W,C contiguous): the columns are blended per tile in registers and consumed by the
     MFMAs directly, a second launch sums the workgroups' partial sums into the weight's own layout (wd_deform_dw_f32)."""
     x = _nhwc(x); offset = _nhwc(offset)
@@ -576,12 +576,12 @@ def deform_dw(x, offset, dy_nhwc, groups):
     L = _lib.lib()
     scratch = torch.empty(L.wd_deform_dw_scratch_floats(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups)), dtype=torch.float32,
                           device=x.device)
-    _lib.check(L.wd_deform_dw_f32(_p(x), _p(offset), _p(dy_nhwc), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups),
-                                  _p(scratch), _p(dw), _stream()), 'wd_deform_dw_f32')
+    _lib.check(L.wd_deform_dw_f32(_p(x), _p(offset), _p(dy_nhwc), _p(y_act) if y_act is not None else None, _p(scale) if scale is not None else None,
+                                  C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups), _p(scratch), _p(dw), _stream()), 'wd_deform_dw_f32')
     return dw
 
 
-def deform_dxoff(x, offset, dy_nhwc, weight, groups):
+def deform_dxoff(x, offset, dy_nhwc, weight, groups, y_act=None, scale=None):
     """(dx (N,C,H,W) channels_last, doffset (N,18,H,W) channels_last) without the dcol slab (wd_deform_dxoff_f32): per tile dcol = dY W on the
     MFMAs, dOffset from the fragment in registers, dX by a gather over the inverted sampling table out of LDS."""
     x = _nhwc(x); offset = _nhwc(offset)
@@ -596,7 +596,8 @@ def deform_dxoff(x, offset, dy_nhwc, weight, groups):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(L.wd_deform_dxoff_f32(_p(x), _p(offset), _p(dy_nhwc), _p(weight.contiguous()), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+    _lib.check(L.wd_deform_dxoff_f32(_p(x), _p(offset), _p(dy_nhwc), _p(y_act) if y_act is not None else None,
+                                     _p(scale) if scale is not None else None, _p(weight.contiguous()), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
                                      C.c_int(groups), _p(tables), _p(packed), _p(dx), _p(doff), _stream()), 'wd_deform_dxoff_f32')
     if log is not None:
         e1.record()
@@ -626,7 +627,15 @@ class DeformConvFn(torch.autograd.Function):
         groups, stride, pad, has_scale, relu = ctx.cfg
         cout, cg = weight.shape[0], weight.shape[1]
         cog = cout // groups
-        if has_scale or relu:                        # epilogue backward in one pass: dy * (y > 0) * scale
+        fused = fused_deform_backward_supported(x.shape[1], cout, groups, stride, pad)
+        # WD_FUSED_DEFORM_EPILOGUE=1: both halves take the epilogue backward on their dY loads instead of the separate masking pass - measured
+        # same-box 80.1 / 80.8 ms per step against 79.0 / 80.2 with the pass (the extra loads sit on the kernels' latency-critical prefetch), so off
+        all_fused = fused and FUSED_DEFORM_DXOFF and os.environ.get('WD_FUSED_DEFORM_EPILOGUE', '0') == '1'
+        y_act = scale_v = None
+        if (has_scale or relu) and all_fused:
+            y_act = _nhwc(y) if relu else None
+            scale_v = scale if has_scale else None
+        elif has_scale or relu:                      # epilogue backward in one pass: dy * (y > 0) * scale
             dyc = _nhwc(dy)
             n_, c_, h_, w_ = dyc.shape
             g = act_bwd(dyc.permute(0, 2, 3, 1).reshape(n_ * h_ * w_, c_), _nhwc(y).permute(0, 2, 3, 1).reshape(n_ * h_ * w_, c_) if relu else None,
@@ -636,16 +645,15 @@ class DeformConvFn(torch.autograd.Function):
         p = dyn.shape[0] * dyn.shape[1] * dyn.shape[2]
         dyg = dyn.reshape(p, groups, cog).permute(1, 0, 2)                      # (G, P, cog) view, row stride Cout
         dx = doff = dw = None
-        fused = fused_deform_backward_supported(x.shape[1], cout, groups, stride, pad)
         if ctx.needs_input_grad[2]:
             if fused:
-                dw = deform_dw(x, offset, dyn.contiguous(), groups)
+                dw = deform_dw(x, offset, dyn.contiguous(), groups, y_act, scale_v)
             else:
                 col = deform_im2col(x, offset, stride, pad, groups).view(groups, p, 9 * cg)
                 dwg = torch.bmm(dyg.transpose(1, 2), col)                       # (G, cog, 9*cg): [g][o][k][i]
                 dw = dwg.view(groups, cog, 9, cg).permute(0, 1, 3, 2).reshape(cout, cg, 3, 3)
         if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and fused and FUSED_DEFORM_DXOFF:
-            dx, doff = deform_dxoff(x, offset, dyn.contiguous(), weight, groups)
+            dx, doff = deform_dxoff(x, offset, dyn.contiguous(), weight, groups, y_act, scale_v)
         elif ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wg = weight.view(groups, cog, cg, 9).permute(0, 1, 3, 2).reshape(groups, cog, 9 * cg)   # [g][o][k][i] (small)
             dcol = torch.bmm(dyg, wg)                                           # (G, P, 9*cg)
