@@ -687,11 +687,12 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
     if (cur_tile >= 0) flush();
 }
 
-// Samples whose corners are not all inside the tile's patch: dcol row by plain dot products (lane = input channel of the group), per-corner
-// global atomics for dX, wave-reduced dOffset.  grid (tiles, 8 group chunks); one wave per sample in turn.
+// Samples whose corners are not all inside the tile's patch: dcol row by plain dot products (lane = input channel of the group; the packed
+// weights make the loads 16 bytes per lane), per-corner global atomics for dX, dOffset reduced over the channel lanes.  grid (tiles, 8 group
+// chunks); 64 / CG samples per wave at a time.
 template <int CG>
 __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
-                                                             const float* __restrict__ scale, const float* __restrict__ w,
+                                                             const float* __restrict__ scale, const float* __restrict__ wpk,
                                                              const unsigned char* __restrict__ tbl, int batch, int H, int W, int C,
                                                              float* __restrict__ dx, float* __restrict__ doff) {
     const unsigned char* tb = tbl + (size_t)blockIdx.x * tt::BYTES;
@@ -704,8 +705,9 @@ __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __rest
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const unsigned* farpos = reinterpret_cast<const unsigned*>(tb + tt::FARPOS);
     const uint4* tab = reinterpret_cast<const uint4*>(tb + tt::TAB);
-    const bool act = lane < CG;
-    const int ci = act ? lane : 0;
+    // 64 / CG samples per wave at a time: lane = (sample slot, input channel of the group)
+    constexpr int R = 64 / CG, MT = CG / 16, KS = CG / 4, KQ = KS / 4;
+    const int sub = lane / CG, ci = lane % CG;
     __shared__ int nlist;
     __shared__ unsigned short list[fb::NE];
     if (tid == 0) nlist = 0;
@@ -714,41 +716,51 @@ __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __rest
         if (farpos[row]) list[atomicAdd(&nlist, 1)] = (unsigned short)row;
     __syncthreads();
     const int nl = nlist;
-    for (int g = blockIdx.y; g < G; g += gridDim.y)
-    for (int li = wave; li < nl; li += 4) {
-        const int row = list[li];
+    for (int lb = wave * R; lb < nl; lb += 4 * R) {
+        const bool valid = lb + sub < nl;
+        const int row = list[valid ? lb + sub : lb];
         const unsigned far = farpos[row];
         const int tap = row >> 6, pixel = row & 63;
         const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);        // inside the image (far is only set for such pixels)
-        const size_t dat = ((size_t)(tn * H + oy) * W + ox) * C + g * CG;
-        float gcol = 0.f;
-        for (int o = 0; o < CG; ++o) {
-            float d = dy[dat + o];
-            if (yact && !(yact[dat + o] > 0.f)) d = 0.f;
-            if (scale) d *= scale[g * CG + o];
-            gcol += d * w[((size_t)(g * CG + o) * CG + ci) * 9 + tap];
-        }
-        if (!act) gcol = 0.f;
         const uint4 e = tab[row];
         const float lh = __uint_as_float(e.z), lw = __uint_as_float(e.w), uh = 1.f - lh, uw = 1.f - lw;
         const int ih = (int)(far & 0xFFFFu) - 32768, iw = (int)(far >> 16) - 32768;
         const float wq[4] = {uh * uw, uh * lw, lh * uw, lh * lw};
-        float v[4];
+        for (int g = blockIdx.y; g < G; g += gridDim.y) {
+            // dcol[ci] = sum_o dY_eff[o] W[o][tap][ci]: the packed weights (MFMA fragment order) give 16 bytes per lane and 4 output channels,
+            // 512 contiguous bytes per 16 lanes; dY is one 16-byte broadcast load per sample slot
+            const size_t dat = ((size_t)(tn * H + oy) * W + ox) * C + g * CG;
+            const float* wp = wpk + ((((size_t)g * 9 + tap) * MT + (ci >> 4)) * 64 + (ci & 15)) * KS;
+            float gcol = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int yy = ih + (q >> 1), xx = iw + (q & 1);
-            const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const size_t at = ((size_t)(tn * H + (in ? yy : 0)) * W + (in ? xx : 0)) * C + g * CG + ci;
-            v[q] = in ? x[at] : 0.f;
-            if (in && act && wq[q] != 0.f) atomicAdd(dx + at, wq[q] * gcol);
-        }
-        float dh = gcol * ((v[2] - v[0]) * uw + (v[3] - v[1]) * lw);
-        float dw = gcol * ((v[1] - v[0]) * uh + (v[3] - v[2]) * lh);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { dh += __shfl_xor(dh, o, 64); dw += __shfl_xor(dw, o, 64); }
-        if (lane == 0) {
-            atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap, dh);
-            atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap + 1, dw);
+                for (int u = 0; u < KQ; ++u) {
+                    const int o0 = KS * j + 4 * u;
+                    f32x4 d = *reinterpret_cast<const f32x4*>(dy + dat + o0);
+                    if (yact) d = fb_mask(d, *reinterpret_cast<const f32x4*>(yact + dat + o0));
+                    if (scale) d = d * *reinterpret_cast<const f32x4*>(scale + g * CG + o0);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + (16 * j) * KS + 4 * u);
+                    gcol += (d[0] * w4[0] + d[1] * w4[1]) + (d[2] * w4[2] + d[3] * w4[3]);
+                }
+            if (!valid) gcol = 0.f;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int yy = ih + (q >> 1), xx = iw + (q & 1);
+                const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                const size_t at = ((size_t)(tn * H + (in ? yy : 0)) * W + (in ? xx : 0)) * C + g * CG + ci;
+                v[q] = in ? x[at] : 0.f;
+                if (in && valid && wq[q] != 0.f) atomicAdd(dx + at, wq[q] * gcol);
+            }
+            float dh = gcol * ((v[2] - v[0]) * uw + (v[3] - v[1]) * lw);
+            float dw = gcol * ((v[1] - v[0]) * uh + (v[3] - v[2]) * lh);
+#pragma unroll
+            for (int o = CG / 2; o > 0; o >>= 1) { dh += __shfl_xor(dh, o, 64); dw += __shfl_xor(dw, o, 64); }
+            if (ci == 0 && valid) {
+                atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap, dh);
+                atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap + 1, dw);
+            }
         }
     }
 }
@@ -832,6 +844,10 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
     if (const char* e = getenv("WD_DXOFF_WGS")) nwg = atoi(e);
     if (nwg > items) nwg = items;
     if (nwg < 1) nwg = 1;
+    int far_chunks = 32;                                     // group chunks of the far-sample kernel (workgroups of tiles without such samples exit at once)
+    if (const char* e = getenv("WD_FAR_CHUNKS")) far_chunks = atoi(e);
+    if (far_chunks < 1) far_chunks = 1;
+    if (far_chunks > groups) far_chunks = groups;
     const int naux = 4 * cus;                                // blocks that zero dX and pack the weights, in the launch that builds the tables
     if (cg == 32) {
         static bool attr = false;
@@ -844,7 +860,7 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
                            packed_weight, dx, doffset);
         hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, y_act, scale, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, y_act, scale, weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, (unsigned)far_chunks), dim3(256), 0, st, x, dy, y_act, scale, packed_weight, tables, batch, h, w, c,
                            dx, doffset);
     } else {
         static bool attr = false;
@@ -857,7 +873,7 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
                            packed_weight, dx, doffset);
         hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, y_act, scale, packed_weight, tables, batch, h,
                            w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, 8u), dim3(256), 0, st, x, dy, y_act, scale, weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, (unsigned)far_chunks), dim3(256), 0, st, x, dy, y_act, scale, packed_weight, tables, batch, h, w, c,
                            dx, doffset);
     }
     WT_HIP(hipGetLastError());
