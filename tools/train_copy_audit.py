@@ -15,7 +15,7 @@ enable_gemm_tuning()
 dev = torch.device('cuda')
 det = Detectron2Det(seed=0).to(dev).train()
 params = training.set_trainable(det.model)
-opt = torch.optim.SGD(params, lr=0.002, momentum=0.9, weight_decay=1e-4)
+opt = torch.optim.SGD(params, lr=0.002, momentum=0.9, weight_decay=1e-4, fused=True)
 g = torch.Generator().manual_seed(0)
 img = torch.randint(0, 256, (1, 3, 886, 1280), generator=g).float().to(dev)
 wh = torch.rand((30, 2), generator=g) * 280 + 20
