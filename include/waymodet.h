@@ -192,20 +192,21 @@ int wd_deform_im2col_f32(const float* x, const float* offset, int batch, int h, 
                          float* col, void* stream);
 int wd_deform_col2im_f32(const float* dcol, const float* x, const float* offset, int batch, int h, int w, int c, int groups,
                          int stride, int pad, float* dx, float* doffset, void* stream);
-/* Fused form of the same backward for stride 1 / pad 1 / C_out = C_in / 16 or 32 channels per group (every stride-1 DeformConv of res3 and
- * res4; round 4): the column slab is never written to HBM.
+/* Fused form of the same backward for pad 1 / stride 1 or 2 / C_out = C_in / 16 or 32 channels per group (every DeformConv of res3 and res4;
+ * round 4): the column slab is never written to HBM.  h, w = the INPUT size; dy / offset / doffset have the output size ((h - 1) / stride + 1).
  *   wd_deform_dw_f32 : dw (C, C/groups, 3, 3) OIHW, the layout of the weight = sum over output pixels of dY[p][o] * col[p][tap][ci]
  *                      (the im2col + dW GEMM pair; dw is overwritten).  dy (N,H,W,C) NHWC. */
 /*   y_act / scale (both may be NULL): the backward of the block's fused epilogue y = relu(conv * scale + bias) applied to dy as it is loaded,
  *                      dy_eff = dy * (y_act > 0) * scale[channel] (y_act (N,H,W,C) = the forward output; instead of a wd_act_bwd_f32 pass).
  *   wd_deform_dxoff_f32 : dx (N,H,W,C) and doffset (N,H,W,18), both overwritten (the dcol GEMM + col2im pair).  weight = the (C, C/groups,
  *                      3, 3) OIHW tensor; tables (wd_deform_bwd_tables_bytes) and packed_weight (C * 9 * C/groups floats) are scratch. */
-size_t wd_deform_bwd_tables_bytes(int batch, int h, int w);
+size_t wd_deform_bwd_tables_bytes(int batch, int h, int w, int stride);
 int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, const float* y_act, const float* scale, const float* weight, int batch,
-                        int h, int w, int c, int groups, unsigned char* tables, float* packed_weight, float* dx, float* doffset, void* stream);
-size_t wd_deform_dw_scratch_floats(int batch, int h, int w, int c, int groups);     /* per-workgroup partial sums (reduced by a second launch) */
+                        int h, int w, int c, int groups, int stride, unsigned char* tables, float* packed_weight, float* dx, float* doffset,
+                        void* stream);
+size_t wd_deform_dw_scratch_floats(int batch, int h, int w, int c, int groups, int stride);     /* per-workgroup partial sums (reduced by a second launch) */
 int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, const float* y_act, const float* scale, int batch, int h, int w, int c,
-                     int groups, float* scratch, float* dw, void* stream);
+                     int groups, int stride, float* scratch, float* dw, void* stream);
 
 /* 3x3 convolution (pad 1) with few output channels as "library GEMM + shift-add" (the 18-channel offset conv in front of
  * every DeformConv, job.log:412): partial (N,H,W,ld) holds, per INPUT pixel, partial[tap*n_out + n] = sum_c x[c]*w[n][c][tap]

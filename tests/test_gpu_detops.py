@@ -164,6 +164,7 @@ def test_deform_conv_backward_vs_autograd_reference(fold_epilogue, monkeypatch):
     from oracle import detector_ref as R
     from waymo_2d_tracking_amd.detnet.nn import ops
     monkeypatch.setenv('WD_FUSED_DEFORM_EPILOGUE', fold_epilogue)      # 1: the fused kernels mask / scale dY themselves (off by default)
+    monkeypatch.setenv('WD_FUSED_DEFORM_S2', fold_epilogue)            # 1: the stride-2 case below takes the fused kernels too (off by default)
     g = torch.Generator().manual_seed(21)
     # stride 1: LDS-accumulating dx kernel (small offsets stay in the patch, the 4.0-scaled case also takes its global
     # path); stride 2: one global atomic per corner value

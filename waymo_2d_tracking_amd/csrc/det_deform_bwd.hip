@@ -20,6 +20,15 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
+// Stride 1 (pad 1): output = input size, the 14 x 14 patch of a tile starts at image pixel 8 t - 3 (2-pixel halo around the 10 x 10 footprint
+// of the undeformed taps).  Stride 2: the footprint is 17 x 17, the patch holds its rows / columns 1 .. 14 (origin 16 t + 1) and the samples of
+// the outer taps (about a third) are "far" - the same split as the forward kernel makes.
+struct Geo {
+    int H, W;        // input (x, dX)
+    int Ho, Wo;      // output (dY, offset, dOffset); tiles are 8 x 8 output pixels
+    int S, org;      // stride; patch origin = image pixel S * 8 * t - org (org = 3 for stride 1, -1 for stride 2)
+};
+
 namespace fb {
 constexpr int PS = 14;                 // patch side: 8 + 2 (3x3 footprint) + 2 * 2 (halo for the learned offsets)
 constexpr int NPIX = PS * PS;          // 196; pixel 196 = zeros (samples / pixels outside the image)
@@ -36,14 +45,15 @@ constexpr int XPAD = 4;                // deform_dxoff_kernel: floats of padding
 // branch-free - and leaves far = (row + 32768) | (column + 32768) << 16 of its upper-left corner in IMAGE coordinates (otherwise 0) for a
 // second pass that only runs for tiles with such samples.
 template <unsigned PB>                     // PB = bytes per patch pixel in the LDS patch buffer
-__device__ __forceinline__ uint4 fb_entry(bool pixel_in_image, int yy, int xx, int kh, int kw, float oy, float ox, int ty, int tx, int H, int W,
+__device__ __forceinline__ uint4 fb_entry(bool pixel_in_image, int yy, int xx, int kh, int kw, float oy, float ox, int ty, int tx, const Geo& G,
                                           unsigned& far) {
+    const int H = G.H, W = G.W;
     unsigned c0 = fb::ZERO, c1 = fb::ZERO, c2 = fb::ZERO, c3 = fb::ZERO;
     float lh = 0.f, lw = 0.f;
     far = 0;
     if (pixel_in_image) {
-        const float ry = (float)(yy + kh + 2) + oy, rx = (float)(xx + kw + 2) + ox;          // patch coordinates
-        const float h_im = ry + (float)(ty * 8 - 3), w_im = rx + (float)(tx * 8 - 3);
+        const float ry = (float)(G.S * yy + kh - 1 + G.org) + oy, rx = (float)(G.S * xx + kw - 1 + G.org) + ox;          // patch coordinates
+        const float h_im = ry + (float)(ty * 8 * G.S - G.org), w_im = rx + (float)(tx * 8 * G.S - G.org);
         if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
             const float fy = floorf(ry), fx = floorf(rx);
             const int hl = (int)fy, wl = (int)fx;
@@ -52,7 +62,7 @@ __device__ __forceinline__ uint4 fb_entry(bool pixel_in_image, int yy, int xx, i
                 const unsigned u = hl * fb::PS + wl;
                 c0 = u; c1 = u + 1; c2 = u + fb::PS; c3 = u + fb::PS + 1;
             } else {
-                far = (unsigned)(hl + ty * 8 - 3 + 32768) | ((unsigned)(wl + tx * 8 - 3 + 32768) << 16);
+                far = (unsigned)(hl + ty * 8 * G.S - G.org + 32768) | ((unsigned)(wl + tx * 8 * G.S - G.org + 32768) << 16);
             }
         }
     }
@@ -84,14 +94,15 @@ __device__ __forceinline__ typename fb_vec<V>::type fb_far_corner(const float* _
 
 // Stage the tile's input patch (one group) and sampling table in LDS.  NTHR threads.  farflag[kh] != 0: kernel row kh has far samples.
 template <int CG, int NTHR>
-__device__ __forceinline__ void fb_stage(const float* __restrict__ x, const float* __restrict__ offset, int tn, int ty, int tx, int H, int W, int C,
+__device__ __forceinline__ void fb_stage(const float* __restrict__ x, const float* __restrict__ offset, int tn, int ty, int tx, const Geo& G, int C,
                                          int c0, float* __restrict__ xs, uint4* __restrict__ tab, unsigned* __restrict__ farpos,
                                          int* __restrict__ farflag, int tid) {
     constexpr int Q = CG / 4;
+    const int H = G.H, W = G.W;
     for (int i = tid; i < fb::NPIX * Q; i += NTHR) {
         const int pp = i / Q, q = i - pp * Q;
         const int r = pp / fb::PS;
-        const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + (pp - r * fb::PS);
+        const int iy = G.S * 8 * ty - G.org + r, ix = G.S * 8 * tx - G.org + (pp - r * fb::PS);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
             v = *reinterpret_cast<const f32x4*>(x + ((size_t)(tn * H + iy) * W + ix) * C + c0 + q * 4);
@@ -100,12 +111,12 @@ __device__ __forceinline__ void fb_stage(const float* __restrict__ x, const floa
     for (int e = tid; e < fb::NE; e += NTHR) {
         const int p = e / 9, k = e - 9 * p;
         const int yy = p >> 3, xx = p & 7, oy = 8 * ty + yy, ox = 8 * tx + xx;
-        const bool in = oy < H && ox < W;
+        const bool in = oy < G.Ho && ox < G.Wo;
         float2 ov = make_float2(0.f, 0.f);
-        if (in) ov = *reinterpret_cast<const float2*>(offset + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * k);
+        if (in) ov = *reinterpret_cast<const float2*>(offset + ((size_t)(tn * G.Ho + oy) * G.Wo + ox) * 18 + 2 * k);
         const int kh = k / 3;
         unsigned far;
-        tab[k * 64 + p] = fb_entry<CG * 4>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, H, W, far);
+        tab[k * 64 + p] = fb_entry<CG * 4>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, G, far);
         farpos[k * 64 + p] = far;
         if (far) farflag[kh] = 1;
     }
@@ -137,7 +148,7 @@ __device__ __forceinline__ typename fb_vec<V>::type fb_sample_far(const uint4 e,
 template <int CG>
 __global__ __launch_bounds__(192) void deform_dw_kernel(const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ dy,
                                                         const float* __restrict__ yact, const float* __restrict__ scale,
-                                                        int batch, int H, int W, int C, int slices, float* __restrict__ part) {
+                                                        int batch, Geo geo, int C, int slices, float* __restrict__ part) {
     constexpr int MT = CG / 16;                  // 16-wide tiles along o and along ci; a lane holds MT consecutive channels (o = MT i + mt)
     using vec = typename fb_vec<MT>::type;
     __shared__ __attribute__((aligned(16))) float xs[(fb::NPIX + 1) * CG];
@@ -147,7 +158,8 @@ __global__ __launch_bounds__(192) void deform_dw_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, j = lane >> 4;
     const int G = C / CG;
     const int g = blockIdx.x % G, slice = blockIdx.x / G;
-    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3, ntiles = batch * tiles_y * tiles_x;
+    const int H = geo.H, W = geo.W, Ho = geo.Ho, Wo = geo.Wo;
+    const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3, ntiles = batch * tiles_y * tiles_x;
     f32x4 acc[3][MT][MT];   // experiments: -DFB_NO_EPILOGUE (no atomics), -DFB_NO_STAGE (stage the first tile only)
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -168,15 +180,15 @@ __global__ __launch_bounds__(192) void deform_dw_kernel(const float* __restrict_
 #ifdef FB_NO_STAGE
         if (tile == slice)
 #endif
-        fb_stage<CG, 192>(x, offset, tn, ty, tx, H, W, C, g * CG, xs, tab, farpos, farflag, tid);
+        fb_stage<CG, 192>(x, offset, tn, ty, tx, geo, C, g * CG, xs, tab, farpos, farflag, tid);
         // A fragments: dY[pixel 4 s + j][o = MT n + mt]  (K = pixels: k-step s covers 4 consecutive pixels of a tile row)
         vec a[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int oy = 8 * ty + (s >> 1), ox = 8 * tx + 4 * (s & 1) + j;
             a[s] = fb_zero<MT>();
-            if (oy < H && ox < W) {
-                const size_t at = ((size_t)(tn * H + oy) * W + ox) * C + g * CG + MT * n;
+            if (oy < Ho && ox < Wo) {
+                const size_t at = ((size_t)(tn * Ho + oy) * Wo + ox) * C + g * CG + MT * n;
                 a[s] = *reinterpret_cast<const vec*>(dy + at);
                 if (yact) a[s] = fb_mask(a[s], *reinterpret_cast<const vec*>(yact + at));
                 if (scale) a[s] = a[s] * sc;
@@ -282,11 +294,12 @@ static_assert(LDS_BYTES % 16 == 0 && INV % 8 == 0 && BYTES % 16 == 0, "table ali
 
 // (the same launch also zeroes dX / dOffset and packs the weights: blocks >= the number of tiles, see below)
 template <int CG>
-__global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __restrict__ offset, int batch, int H, int W, unsigned char* __restrict__ tbl,
+__global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __restrict__ offset, int batch, Geo geo, unsigned char* __restrict__ tbl,
                                                                 const float* __restrict__ weight, int C, float* __restrict__ wpk,
                                                                 float* __restrict__ dx, float* __restrict__ doff) {
+    const int H = geo.H, W = geo.W, Ho = geo.Ho, Wo = geo.Wo;
     {
-        const int ntiles = batch * ((H + 7) >> 3) * ((W + 7) >> 3);
+        const int ntiles = batch * ((Ho + 7) >> 3) * ((Wo + 7) >> 3);
         if ((int)blockIdx.x >= ntiles) {
             // auxiliary blocks: dX = 0 (the gather adds into it), and the weights (C_out, CG, 3, 3) OIHW in MFMA A-fragment order:
             // wpk[g][tap][mt][lane = 16 j + n][s] = W[g CG + (CG / 4) j + s][mt 16 + n][tap]
@@ -315,7 +328,7 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
     __shared__ int nfar;
     constexpr unsigned PB = (CG + fb::XPAD) * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
     const int tile = blockIdx.x;
     const int tn = tile / (tiles_y * tiles_x), trem = tile - tn * tiles_y * tiles_x;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -331,19 +344,19 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = pp[q] / fb::PS, cc = pp[q] - r * fb::PS;
-            const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + cc;
+            const int iy = geo.S * 8 * ty - geo.org + r, ix = geo.S * 8 * tx - geo.org + cc;
             use[q] = pp[q] != (unsigned)fb::ZERO && wq[q] != 0.f && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         }
     };
     for (int e = tid; e < fb::NE; e += 256) {
         const int p = e / 9, k = e - 9 * p;
         const int yy = p >> 3, xx = p & 7, oy = 8 * ty + yy, ox = 8 * tx + xx;
-        const bool in = oy < H && ox < W;
+        const bool in = oy < Ho && ox < Wo;
         float2 ov = make_float2(0.f, 0.f);
-        if (in) ov = *reinterpret_cast<const float2*>(offset + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * k);
+        if (in) ov = *reinterpret_cast<const float2*>(offset + ((size_t)(tn * Ho + oy) * Wo + ox) * 18 + 2 * k);
         const int kh = k / 3;
         unsigned far;
-        const uint4 en = fb_entry<PB>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, H, W, far);
+        const uint4 en = fb_entry<PB>(in, yy, xx, kh, k - 3 * kh, ov.x, ov.y, ty, tx, geo, far);
         tab[k * 64 + p] = en;
         farpos[k * 64 + p] = far;
         if (far) atomicAdd(&nfar, 1);
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(256) void deform_bwd_tables_kernel(const float* __r
     if (tid == 0) *reinterpret_cast<unsigned*>(out + tt::NFAR) = (unsigned)nfar;
     for (int i = tid; i < 64 * 18; i += 256) {             // dOffset of the tile = 0 (the dX / dOffset kernels add into it)
         const int pixel = i / 18, oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);
-        if (oy < H && ox < W) doff[((size_t)(tn * H + oy) * W + ox) * 18 + (i - pixel * 18)] = 0.f;
+        if (oy < Ho && ox < Wo) doff[((size_t)(tn * Ho + oy) * Wo + ox) * 18 + (i - pixel * 18)] = 0.f;
     }
 }
 
@@ -451,7 +464,7 @@ template <int CG> constexpr size_t dxoff_smem_bytes() { return (size_t)(fb::NPIX
 template <int CG>
 __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                     const float* __restrict__ yact, const float* __restrict__ scale, const float* __restrict__ wpk,
-                                                           const unsigned char* __restrict__ tbl, int batch, int H, int W, int C, int items_total,
+                                                           const unsigned char* __restrict__ tbl, int batch, Geo geo, int C, int items_total,
                                                            float* __restrict__ dx, float* __restrict__ doff) {
     constexpr int MT = CG / 16, KS = CG / 4, KQ = KS / 4;       // k-steps of 4 output channels; float4s per operand fragment
     constexpr int XP = CG + fb::XPAD;                           // patch pitch in floats
@@ -466,7 +479,8 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
     const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int kh = wave % 3, half = wave / 3;
     const int G = C / CG;
-    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const int H = geo.H, W = geo.W, Ho = geo.Ho, Wo = geo.Wo;
+    const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
     int tid = tid0, lane = tid0 & 63, n = lane & 15, j = lane >> 4;
     const long i0 = (long)blockIdx.x * items_total / gridDim.x, i1 = (long)(blockIdx.x + 1) * items_total / gridDim.x;
     int cur_tile = -1, tn = 0, ty = 0, tx = 0;
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
             const float* q = sc + (((pt >> 1) * 3 + fkh) * 12 + (t * 2 + (pt & 1)) * 2 + d) * 64 + pn;
             const float v = (q[0] + q[16]) + (q[32] + q[48]);
             const int oy = 8 * ty + (pixel >> 3), ox = 8 * tx + (pixel & 7);
-            if (oy < H && ox < W) atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + c18, v);
+            if (oy < Ho && ox < Wo) atomicAdd(doff + ((size_t)(tn * Ho + oy) * Wo + ox) * 18 + c18, v);
         }
     };
 
@@ -512,7 +526,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
             const int i = tid + 384 * u;
             const int pp = i / Q, q = i - pp * Q;
             const int r = pp / fb::PS;
-            const int iy = 8 * pty - 3 + r, ix = 8 * ptx - 3 + (pp - r * fb::PS);
+            const int iy = geo.S * 8 * pty - geo.org + r, ix = geo.S * 8 * ptx - geo.org + (pp - r * fb::PS);
             xp[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (i < fb::NPIX * Q && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
                 xp[u] = *reinterpret_cast<const f32x4*>(x + ((size_t)(ptn * H + iy) * W + ix) * C + pg * CG + q * 4);
@@ -522,12 +536,12 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
         for (int p2 = 0; p2 < 2; ++p2) {
             const int pixel = (2 * half + p2) * 16 + n;
             const int oy = 8 * pty + (pixel >> 3), ox = 8 * ptx + (pixel & 7);
-            const bool in = oy < H && ox < W;
+            const bool in = oy < Ho && ox < Wo;
 #pragma unroll
             for (int u = 0; u < KQ; ++u) {
                 bq[p2][u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (in) {
-                    const size_t at = ((size_t)(ptn * H + oy) * W + ox) * C + pg * CG + KS * j + 4 * u;
+                    const size_t at = ((size_t)(ptn * Ho + oy) * Wo + ox) * C + pg * CG + KS * j + 4 * u;
                     bq[p2][u] = *reinterpret_cast<const f32x4*>(dy + at);
                     // backward of the block's fused epilogue on the fly: dY_eff = dY * (y > 0) * scale[channel]
                     if (yact) bq[p2][u] = fb_mask(bq[p2][u], *reinterpret_cast<const f32x4*>(yact + at));
@@ -667,7 +681,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
                         }
                         if (n1 > n0) {
                             const int r = pp / fb::PS;
-                            const int iy = 8 * ty - 3 + r, ix = 8 * tx - 3 + (pp - r * fb::PS);
+                            const int iy = geo.S * 8 * ty - geo.org + r, ix = geo.S * 8 * tx - geo.org + (pp - r * fb::PS);
                             float* d = dx + ((size_t)(tn * H + iy) * W + ix) * C + g * CG + mt * 16 + 4 * c;
 #ifdef FB_NO_DXATOMIC
                             *reinterpret_cast<f32x4*>(d) = a;
@@ -693,13 +707,14 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
 template <int CG>
 __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
                                                              const float* __restrict__ scale, const float* __restrict__ wpk,
-                                                             const unsigned char* __restrict__ tbl, int batch, int H, int W, int C,
+                                                             const unsigned char* __restrict__ tbl, int batch, Geo geo, int C,
                                                              float* __restrict__ dx, float* __restrict__ doff) {
+    const int H = geo.H, W = geo.W, Ho = geo.Ho, Wo = geo.Wo;
     const unsigned char* tb = tbl + (size_t)blockIdx.x * tt::BYTES;
     if (*reinterpret_cast<const unsigned*>(tb + tt::NFAR) == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = C / CG;
-    const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
+    const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
     const int tile = blockIdx.x;
     const int tn = tile / (tiles_y * tiles_x), trem = tile - tn * tiles_y * tiles_x;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __rest
         for (int g = blockIdx.y; g < G; g += gridDim.y) {
             // dcol[ci] = sum_o dY_eff[o] W[o][tap][ci]: the packed weights (MFMA fragment order) give 16 bytes per lane and 4 output channels,
             // 512 contiguous bytes per 16 lanes; dY is one 16-byte broadcast load per sample slot
-            const size_t dat = ((size_t)(tn * H + oy) * W + ox) * C + g * CG;
+            const size_t dat = ((size_t)(tn * Ho + oy) * Wo + ox) * C + g * CG;
             const float* wp = wpk + ((((size_t)g * 9 + tap) * MT + (ci >> 4)) * 64 + (ci & 15)) * KS;
             float gcol = 0.f;
 #pragma unroll
@@ -758,26 +773,35 @@ __global__ __launch_bounds__(256) void deform_bwd_far_kernel(const float* __rest
 #pragma unroll
             for (int o = CG / 2; o > 0; o >>= 1) { dh += __shfl_xor(dh, o, 64); dw += __shfl_xor(dw, o, 64); }
             if (ci == 0 && valid) {
-                atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap, dh);
-                atomicAdd(doff + ((size_t)(tn * H + oy) * W + ox) * 18 + 2 * tap + 1, dw);
+                atomicAdd(doff + ((size_t)(tn * Ho + oy) * Wo + ox) * 18 + 2 * tap, dh);
+                atomicAdd(doff + ((size_t)(tn * Ho + oy) * Wo + ox) * 18 + 2 * tap + 1, dw);
             }
         }
     }
 }
 
-int check_fused(const char* who, int c, int groups, int h, int w) {
+int check_fused(const char* who, int c, int groups, int h, int w, int stride) {
     const int cg = groups > 0 ? c / groups : 0;
-    if (groups < 1 || c % groups || (cg != 16 && cg != 32) || h < 1 || w < 1) {
-        wt::set_error("%s: 16 or 32 channels per group only (C=%d groups=%d)", who, c, groups);
+    if (groups < 1 || c % groups || (cg != 16 && cg != 32) || h < 1 || w < 1 || (stride != 1 && stride != 2)) {
+        wt::set_error("%s: 16 or 32 channels per group, stride 1 or 2 only (C=%d groups=%d stride=%d)", who, c, groups, stride);
         return WT_ERR_INVALID;
     }
     return WT_OK;
 }
 
+// 3 x 3, pad 1: output size and patch origin of a stride
+Geo make_geo(int h, int w, int stride) {
+    Geo g;
+    g.H = h; g.W = w; g.S = stride;
+    g.Ho = (h + 2 - 3) / stride + 1; g.Wo = (w + 2 - 3) / stride + 1;
+    g.org = stride == 1 ? 3 : -1;
+    return g;
+}
+int geo_tiles(const Geo& g, int batch) { return batch * ((g.Ho + 7) / 8) * ((g.Wo + 7) / 8); }
+
 // Tile slices per group: every workgroup resident at once (4 per CU at 32 channels per group - 34 KB of LDS, 3 waves each; 6 at 16), the
 // tiles spread evenly over the slices.
-int fused_dw_slices(int batch, int h, int w, int groups, int cg) {
-    const int ntiles = batch * ((h + 7) / 8) * ((w + 7) / 8);
+int fused_dw_slices(int ntiles, int groups, int cg) {
     const int target = (cg == 32 ? 4 : 6) * 256;
     int per_wg = (int)(((long)ntiles * groups + target - 1) / target);
     if (const char* e = getenv("WD_DW_TILES_PER_WG")) per_wg = atoi(e);
@@ -789,25 +813,26 @@ int fused_dw_slices(int batch, int h, int w, int groups, int cg) {
 
 extern "C" {
 
-size_t wd_deform_dw_scratch_floats(int batch, int h, int w, int c, int groups) {
-    if (groups < 1 || c % groups) return 0;
+size_t wd_deform_dw_scratch_floats(int batch, int h, int w, int c, int groups, int stride) {
+    if (groups < 1 || c % groups || stride < 1) return 0;
     const int cg = c / groups;
-    return (size_t)fused_dw_slices(batch, h, w, groups, cg) * groups * 9 * cg * cg;
+    return (size_t)fused_dw_slices(geo_tiles(make_geo(h, w, stride), batch), groups, cg) * groups * 9 * cg * cg;
 }
 
 int wd_deform_dw_f32(const float* x, const float* offset, const float* dy, const float* y_act, const float* scale, int batch, int h, int w, int c,
-                     int groups, float* scratch, float* dw, void* stream) {
+                     int groups, int stride, float* scratch, float* dw, void* stream) {
     WT_TRY(wt::ensure_device());
-    WT_TRY(check_fused("wd_deform_dw_f32", c, groups, h, w));
+    WT_TRY(check_fused("wd_deform_dw_f32", c, groups, h, w, stride));
     const int cg = c / groups;
     hipStream_t st = (hipStream_t)stream;
-    const int slices = fused_dw_slices(batch, h, w, groups, cg);
+    const Geo geo = make_geo(h, w, stride);
+    const int slices = fused_dw_slices(geo_tiles(geo, batch), groups, cg);
     const int nred = (groups * 9 * cg * cg + 255) / 256;
     if (cg == 32) {
-        hipLaunchKernelGGL(deform_dw_kernel<32>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, y_act, scale, batch, h, w, c, slices, scratch);
+        hipLaunchKernelGGL(deform_dw_kernel<32>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, y_act, scale, batch, geo, c, slices, scratch);
         hipLaunchKernelGGL(deform_dw_reduce_kernel<32>, dim3((unsigned)nred), dim3(256), 0, st, scratch, groups, slices, dw);
     } else {
-        hipLaunchKernelGGL(deform_dw_kernel<16>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, y_act, scale, batch, h, w, c, slices, scratch);
+        hipLaunchKernelGGL(deform_dw_kernel<16>, dim3((unsigned)(groups * slices)), dim3(192), 0, st, x, offset, dy, y_act, scale, batch, geo, c, slices, scratch);
         hipLaunchKernelGGL(deform_dw_reduce_kernel<16>, dim3((unsigned)nred), dim3(256), 0, st, scratch, groups, slices, dw);
     }
     WT_HIP(hipGetLastError());
@@ -822,15 +847,19 @@ int wd_deform_fb_ticks(unsigned long long* out8, int reset) {
 }
 #endif
 
-size_t wd_deform_bwd_tables_bytes(int batch, int h, int w) { return (size_t)batch * ((h + 7) / 8) * ((w + 7) / 8) * tt::BYTES; }
+size_t wd_deform_bwd_tables_bytes(int batch, int h, int w, int stride) {
+    return stride < 1 ? 0 : (size_t)geo_tiles(make_geo(h, w, stride), batch) * tt::BYTES;
+}
 
 int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, const float* y_act, const float* scale, const float* weight, int batch,
-                        int h, int w, int c, int groups, unsigned char* tables, float* packed_weight, float* dx, float* doffset, void* stream) {
+                        int h, int w, int c, int groups, int stride, unsigned char* tables, float* packed_weight, float* dx, float* doffset,
+                        void* stream) {
     WT_TRY(wt::ensure_device());
-    WT_TRY(check_fused("wd_deform_dxoff_f32", c, groups, h, w));
+    WT_TRY(check_fused("wd_deform_dxoff_f32", c, groups, h, w, stride));
     const int cg = c / groups;
     hipStream_t st = (hipStream_t)stream;
-    const int ntiles = batch * ((h + 7) / 8) * ((w + 7) / 8);
+    const Geo geo = make_geo(h, w, stride);
+    const int ntiles = geo_tiles(geo, batch);
     const int items = ntiles * groups;
     static int cus = 0;
     if (!cus) {
@@ -856,11 +885,11 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
                                        (int)dxoff_smem_bytes<32>()));
             attr = true;
         }
-        hipLaunchKernelGGL(deform_bwd_tables_kernel<32>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, h, w, tables, weight, c,
+        hipLaunchKernelGGL(deform_bwd_tables_kernel<32>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, geo, tables, weight, c,
                            packed_weight, dx, doffset);
-        hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, y_act, scale, packed_weight, tables, batch, h,
-                           w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, (unsigned)far_chunks), dim3(256), 0, st, x, dy, y_act, scale, packed_weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, y_act, scale, packed_weight, tables, batch, geo,
+                           c, items, dx, doffset);
+        hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, (unsigned)far_chunks), dim3(256), 0, st, x, dy, y_act, scale, packed_weight, tables, batch, geo, c,
                            dx, doffset);
     } else {
         static bool attr = false;
@@ -869,11 +898,11 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
                                        (int)dxoff_smem_bytes<16>()));
             attr = true;
         }
-        hipLaunchKernelGGL(deform_bwd_tables_kernel<16>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, h, w, tables, weight, c,
+        hipLaunchKernelGGL(deform_bwd_tables_kernel<16>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, geo, tables, weight, c,
                            packed_weight, dx, doffset);
-        hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, y_act, scale, packed_weight, tables, batch, h,
-                           w, c, items, dx, doffset);
-        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, (unsigned)far_chunks), dim3(256), 0, st, x, dy, y_act, scale, packed_weight, tables, batch, h, w, c,
+        hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, y_act, scale, packed_weight, tables, batch, geo,
+                           c, items, dx, doffset);
+        hipLaunchKernelGGL(deform_bwd_far_kernel<16>, dim3((unsigned)ntiles, (unsigned)far_chunks), dim3(256), 0, st, x, dy, y_act, scale, packed_weight, tables, batch, geo, c,
                            dx, doffset);
     }
     WT_HIP(hipGetLastError());

@@ -562,11 +562,14 @@ FUSED_DEFORM_DXOFF = os.environ.get('WD_FUSED_DEFORM_DXOFF', '1') != '0'       #
 
 
 def fused_deform_backward_supported(c, cout, groups, stride, pad):
-    """The fused kernels (csrc/det_deform_bwd.hip) cover the stride-1 DeformConvs of res3 / res4: 16 or 32 channels per group."""
-    return FUSED_DEFORM_BACKWARD and stride == 1 and pad == 1 and c == cout and c % groups == 0 and c // groups in (16, 32)
+    """The fused kernels (csrc/det_deform_bwd.hip) cover the stride-1 DeformConvs of res3 / res4: 16 or 32 channels per group.  They also run
+    stride 2 (WD_FUSED_DEFORM_S2=1; the 14 x 14 patch then holds the middle of the 17 x 17 footprint and a third of the samples goes through the
+    per-sample kernel) - measured no faster than the column-slab form (1231 / 609 us against 1171 / 585 us for the res3 / res4 layer), so off."""
+    return (FUSED_DEFORM_BACKWARD and (stride == 1 or (stride == 2 and os.environ.get('WD_FUSED_DEFORM_S2', '0') == '1')) and pad == 1
+            and c == cout and c % groups == 0 and c // groups in (16, 32))
 
 
-def deform_dw(x, offset, dy_nhwc, groups, y_act=None, scale=None):
+def deform_dw(x, offset, dy_nhwc, groups, y_act=None, scale=None, stride=1):
     """dW (C, C/groups, 3, 3) from x, offset and dy (N,H,W,C contiguous): the columns are blended per tile in registers and consumed by the
     MFMAs directly, a second launch sums the workgroups' partial sums into the weight's own layout (wd_deform_dw_f32)."""
     x = _nhwc(x); offset = _nhwc(offset)
@@ -574,20 +577,21 @@ def deform_dw(x, offset, dy_nhwc, groups, y_act=None, scale=None):
     cg = c // groups
     dw = torch.empty((c, cg, 3, 3), dtype=torch.float32, device=x.device)
     L = _lib.lib()
-    scratch = torch.empty(L.wd_deform_dw_scratch_floats(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups)), dtype=torch.float32,
-                          device=x.device)
+    scratch = torch.empty(L.wd_deform_dw_scratch_floats(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups), C.c_int(stride)),
+                          dtype=torch.float32, device=x.device)
     _lib.check(L.wd_deform_dw_f32(_p(x), _p(offset), _p(dy_nhwc), _p(y_act) if y_act is not None else None, _p(scale) if scale is not None else None,
-                                  C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups), _p(scratch), _p(dw), _stream()), 'wd_deform_dw_f32')
+                                  C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(groups), C.c_int(stride), _p(scratch), _p(dw), _stream()),
+               'wd_deform_dw_f32')
     return dw
 
 
-def deform_dxoff(x, offset, dy_nhwc, weight, groups, y_act=None, scale=None):
+def deform_dxoff(x, offset, dy_nhwc, weight, groups, y_act=None, scale=None, stride=1):
     """(dx (N,C,H,W) channels_last, doffset (N,18,H,W) channels_last) without the dcol slab (wd_deform_dxoff_f32): per tile dcol = dY W on the
     MFMAs, dOffset from the fragment in registers, dX by a gather over the inverted sampling table out of LDS."""
     x = _nhwc(x); offset = _nhwc(offset)
     n, c, h, w = x.shape
     L = _lib.lib()
-    tables = torch.empty(L.wd_deform_bwd_tables_bytes(C.c_int(n), C.c_int(h), C.c_int(w)), dtype=torch.uint8, device=x.device)
+    tables = torch.empty(L.wd_deform_bwd_tables_bytes(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(stride)), dtype=torch.uint8, device=x.device)
     packed = torch.empty(weight.numel(), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x, memory_format=torch.channels_last)
     doff = torch.empty_like(offset, memory_format=torch.channels_last)
@@ -598,11 +602,13 @@ def deform_dxoff(x, offset, dy_nhwc, weight, groups, y_act=None, scale=None):
         e0.record()
     _lib.check(L.wd_deform_dxoff_f32(_p(x), _p(offset), _p(dy_nhwc), _p(y_act) if y_act is not None else None,
                                      _p(scale) if scale is not None else None, _p(weight.contiguous()), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
-                                     C.c_int(groups), _p(tables), _p(packed), _p(dx), _p(doff), _stream()), 'wd_deform_dxoff_f32')
+                                     C.c_int(groups), C.c_int(stride), _p(tables), _p(packed), _p(dx), _p(doff), _stream()), 'wd_deform_dxoff_f32')
     if log is not None:
         e1.record()
         # algorithmic flops: dcol = dY W per group on the f32 MFMAs (the gather and the dOffset dot products are VALU work on top)
-        log.append(('deform_dxoff (tables + dX gather + dOffset + far samples): C=%d %dx%d' % (c, h, w), 2.0 * n * h * w * 9 * (c // groups) * c, e0, e1))
+        ho, wo = offset.shape[2], offset.shape[3]
+        log.append(('deform_dxoff (tables + dX gather + dOffset + far samples): C=%d %dx%d%s' % (c, ho, wo, ' s2' if stride == 2 else ''),
+                    2.0 * n * ho * wo * 9 * (c // groups) * c, e0, e1))
     return dx, doff
 
 
@@ -647,13 +653,13 @@ class DeformConvFn(torch.autograd.Function):
         dx = doff = dw = None
         if ctx.needs_input_grad[2]:
             if fused:
-                dw = deform_dw(x, offset, dyn.contiguous(), groups, y_act, scale_v)
+                dw = deform_dw(x, offset, dyn.contiguous(), groups, y_act, scale_v, stride)
             else:
                 col = deform_im2col(x, offset, stride, pad, groups).view(groups, p, 9 * cg)
                 dwg = torch.bmm(dyg.transpose(1, 2), col)                       # (G, cog, 9*cg): [g][o][k][i]
                 dw = dwg.view(groups, cog, 9, cg).permute(0, 1, 3, 2).reshape(cout, cg, 3, 3)
         if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and fused and FUSED_DEFORM_DXOFF:
-            dx, doff = deform_dxoff(x, offset, dyn.contiguous(), weight, groups, y_act, scale_v)
+            dx, doff = deform_dxoff(x, offset, dyn.contiguous(), weight, groups, y_act, scale_v, stride)
         elif ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wg = weight.view(groups, cog, cg, 9).permute(0, 1, 3, 2).reshape(groups, cog, 9 * cg)   # [g][o][k][i] (small)
             dcol = torch.bmm(dyg, wg)                                           # (G, P, 9*cg)
