@@ -1,4 +1,5 @@
-// Fused deformable-conv backward for the training graph, stride 1 / pad 1, 16 or 32 channels per group, gfx950.
+// Fused deformable-conv backward for the training graph, pad 1, stride 1 (default) or 2, 16 or 32 channels per
+// group, gfx950.
 // detectron2's CUDA op (deformable_im2col -> GEMM -> deformable_col2im / col2im_coord) materialises the 9*C*P column slab three times per
 // layer; det_backward.hip restates that form (5 passes over the slab, gather-bound through L1: tools/deform_bwd_bench.py).  Here the columns
 // never leave the CU:
@@ -6,9 +7,11 @@
 //     and a slice of the 8x8-pixel tiles; per tile it stages the 14x14xCG input patch (zero-filled outside the image) and the sampling
 //     table of the tile in LDS, blends the column fragment of (4 pixels x 16 channels) in registers and feeds it to
 //     v_mfma_f32_16x16x4_f32 as the B operand with K = pixels; dY is the A operand straight from global memory (one 8-byte load per
-//     k-step, reused by the wave's three taps).  The 9 x CG x CG accumulators stay in registers across the slice and are added to dW with
-//     one float atomic per element and workgroup.
-// Samples whose corners leave the patch (|offset| > ~2 px) fetch their corners from global memory (per lane, rare).
+//     k-step, reused by the wave's three taps).  The 9 x CG x CG accumulators stay in registers across the slice, go out as coalesced
+//     partial sums and deform_dw_reduce_kernel adds the slices into the weight's own OIHW layout (float atomics with this access
+//     pattern cost 44 us per layer).  Samples whose corners leave the patch (|offset| > ~2 px) are zero in the main loop and added by
+//     a second pass with their corners from global memory (only for tiles that have such samples).
+//   * dX / dOffset: deform_bwd_tables_kernel, deform_dxoff_kernel, deform_bwd_far_kernel - see the comment in front of namespace tt.
 // Same arithmetic as det_backward.hip up to the summation order (tests/test_gpu_detops.py compares both with the float64 restatement).
 #include <cstdlib>
 #include <type_traits>
