@@ -204,6 +204,17 @@ def test_launcher_environment_and_refusal(tmp_path):
     assert sorted(L.adopt_rank_caches(3, 8, environ=env, scratch=str(tmp_path / 'tr'))) == ['MIOPEN_USER_DB_PATH', 'WT_TUNABLEOP_OUT']
     assert env['MIOPEN_CUSTOM_CACHE_DIR'] == '/mine' and 'rank3_of_8' in env['MIOPEN_USER_DB_PATH'] and os.path.isdir(env['MIOPEN_USER_DB_PATH'])
     assert os.path.isdir(os.path.dirname(env['WT_TUNABLEOP_OUT']))
+    # a rank's private MIOpen locations start from what a single-process run left in the default ones (same find results on every rank);
+    # a destination that already holds files is left alone, a fresh box has nothing to copy
+    home = tmp_path / 'home'
+    (home / '.config' / 'miopen').mkdir(parents=True)
+    (home / '.config' / 'miopen' / 'gfx950.udb.txt').write_text('find results')
+    dest = {'MIOPEN_USER_DB_PATH': str(tmp_path / 'seed' / 'db'), 'MIOPEN_CUSTOM_CACHE_DIR': str(tmp_path / 'seed' / 'cache')}
+    assert L.seed_rank_cache(dest, home=str(home)) == 1
+    assert open(os.path.join(dest['MIOPEN_USER_DB_PATH'], 'gfx950.udb.txt')).read() == 'find results'
+    (home / '.config' / 'miopen' / 'gfx950.udb.txt').write_text('newer')
+    assert L.seed_rank_cache(dest, home=str(home)) == 0 and open(os.path.join(dest['MIOPEN_USER_DB_PATH'], 'gfx950.udb.txt')).read() == 'find results'
+    assert L.seed_rank_cache({'MIOPEN_USER_DB_PATH': str(tmp_path / 'x')}, home=str(tmp_path / 'nohome')) == 0
     # WT_FORCE_DIST=1 without a launcher: only the rendezvous variables are adopted, a user's thread count survives
     saved = dict(os.environ)
     try:

@@ -48,6 +48,29 @@ def per_rank_cache_env(rank, n_ranks, scratch=None):
             'WT_TUNABLEOP_OUT': os.path.join(d, 'tunableop.csv')}
 
 
+def seed_rank_cache(env, home=None):
+    """Start a rank's private MIOpen locations from what a single-process run on this box left in the default ones (find results in
+    ~/.config/miopen, compiled kernels in ~/.cache/miopen): the ranks then skip the find / compile work of the warm-up AND pick the same
+    solvers (find-mode results vary run to run, which would make some ranks slower than others).  Nothing to copy on a fresh box; a
+    destination that already holds files is left alone.  Returns the number of directories seeded."""
+    import shutil
+    home = home or os.path.expanduser('~')
+    n = 0
+    for key, default in (('MIOPEN_USER_DB_PATH', os.path.join(home, '.config', 'miopen')),
+                         ('MIOPEN_CUSTOM_CACHE_DIR', os.path.join(home, '.cache', 'miopen'))):
+        dest = env.get(key)
+        if not dest or not os.path.isdir(default) or os.path.abspath(dest) == os.path.abspath(default):
+            continue
+        try:
+            if os.path.isdir(dest) and os.listdir(dest):
+                continue
+            shutil.copytree(default, dest, dirs_exist_ok=True)
+            n += 1
+        except OSError:
+            pass                                     # a cache is an optimisation: the rank starts cold instead
+    return n
+
+
 def adopt_rank_caches(rank, n_ranks, environ=None, scratch=None):
     """In-process form of per_rank_cache_env for ranks somebody else started (torchrun): point this process's library caches at its
     own directories before MIOpen / TunableOp initialise.  A location the user exported wins.  Returns the keys it set."""
@@ -59,6 +82,7 @@ def adopt_rank_caches(rank, n_ranks, environ=None, scratch=None):
         environ[k] = v
         os.makedirs(os.path.dirname(v) if k == 'WT_TUNABLEOP_OUT' else v, exist_ok=True)
         taken.append(k)
+    seed_rank_cache({k: environ[k] for k in taken})
     return taken
 
 
@@ -74,13 +98,16 @@ def rank_environments(n_ranks, port, base_env=None, scratch=None):
         e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this pool (RCCL needs it)
         e.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n_ranks)))
         if n_ranks > 1:
+            mine = {}
             for k, v in per_rank_cache_env(r, n_ranks, scratch).items():
                 if k not in e:
                     e[k] = v
+                    mine[k] = v
                     if k != 'WT_TUNABLEOP_OUT':
                         os.makedirs(v, exist_ok=True)
                     else:
                         os.makedirs(os.path.dirname(v), exist_ok=True)
+            seed_rank_cache(mine, home=e.get('HOME'))
         envs.append(e)
     return envs
 
