@@ -26,6 +26,6 @@ for (Cn, G, H, W) in ((1024, 32, 56, 80), (512, 32, 112, 160)):
     L.wd_deform_fb_ticks(t, 1)
     nwg = min(512, (H // 8) * (W // 8) * G)
     tot = sum(t[:6])
-    print('C=%d %dx%d: %d workgroups, %.0f cycles (100 MHz counter ticks x ?) per workgroup' % (Cn, H, W, nwg, tot / nwg))
+    print('C=%d %dx%d: %d workgroups, %.0f s_memtime ticks per workgroup (wave 0)' % (Cn, H, W, nwg, tot / nwg))
     for k in range(6):
         print('   %5.1f %%  %9.0f  %s' % (100.0 * t[k] / tot, t[k] / nwg, NAMES[k]))
