@@ -485,7 +485,12 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
     const int H = geo.H, W = geo.W, Ho = geo.Ho, Wo = geo.Wo;
     const int tiles_x = (Wo + 7) >> 3, tiles_y = (Ho + 7) >> 3;
     int tid = tid0, lane = tid0 & 63, n = lane & 15, j = lane >> 4;
-    const long i0 = (long)blockIdx.x * items_total / gridDim.x, i1 = (long)(blockIdx.x + 1) * items_total / gridDim.x;
+    // work is split at the granularity of a 16-channel phase (MT per item): 2240 items over 512 workgroups would be 4 or 5 items each (the 5 set
+    // the time), 4480 phases are 8 or 9.  A workgroup's first / last item can be a partial one; two workgroups then stage the same patch.
+    const long ph_total = (long)items_total * MT;
+    const long p0 = (long)blockIdx.x * ph_total / gridDim.x, p1 = (long)(blockIdx.x + 1) * ph_total / gridDim.x;
+    if (p0 >= p1) return;
+    const long i0 = p0 / MT, i1 = (p1 + MT - 1) / MT;
     int cur_tile = -1, tn = 0, ty = 0, tx = 0;
     float od[3][2][2];
 #ifdef FB_TIMING
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
     if (i0 < i1) {
         const int ftile = (int)(i0 / G), fg = (int)(i0 - (long)ftile * G);
         load_item(ftile, fg);
-        load_w(fg, 0, 3 * kh);
+        load_w(fg, (int)(p0 - i0 * MT), 3 * kh);
     }
     for (long item = i0; item < i1; ++item) {
         // the lane id goes through an opaque asm once per item: otherwise LLVM hoists ~60 registers of lane-dependent addresses out of this
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
         const int tile = (int)(item / G), g = (int)(item - (long)tile * G);
         const int ntile = (int)((item + 1) / G), ng = (int)(item + 1 - (long)ntile * G);       // the next item (prefetch)
         const bool more = item + 1 < i1;
+        const int mt_begin = (int)(p0 > item * MT ? p0 - item * MT : 0), mt_end = (int)(p1 - item * MT < MT ? p1 - item * MT : MT);
         if (tile != cur_tile) {
             if (cur_tile >= 0) flush();
             FB_BARRIER();
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
         FB_BARRIER();
         FB_T(1);
 #pragma unroll 1
-        for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = mt_begin; mt < mt_end; ++mt) {
             const char* cb = reinterpret_cast<const char*>(xs + mt * 16 + 4 * j);
             const int row0 = 3 * kh * 64 + 2 * half * 16 + n;                     // unit (t, p2): row0 + 64 t + 16 p2
             uint4 en = tab[row0];
@@ -608,8 +614,8 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
 #pragma unroll
                 for (int u = 0; u < KQ; ++u) aq[u] = aqn[u];
                 if (t < 2) load_w(g, mt, tap + 1);
-                else if (mt + 1 < MT) load_w(g, mt + 1, 3 * kh);
-                else if (more) load_w(ng, 0, 3 * kh);
+                else if (mt + 1 < mt_end) load_w(g, mt + 1, 3 * kh);
+                else if (more) load_w(ng, 0, 3 * kh);                            // only a workgroup's first item can start at a later phase
 #pragma unroll
                 for (int p2 = 0; p2 < 2; ++p2) {
                     const int row = row0 + 64 * t + 16 * p2;
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
             FB_T(2);
             FB_BARRIER();
             FB_T(3);
-            if (mt + 1 == MT && more) load_item(ntile, ng);        // in flight during the gather; bq is dead after the last MFMA phase
+            if (mt + 1 == mt_end && more) load_item(ntile, ng);    // in flight during the gather; bq is dead after the last MFMA phase
             // gather: patch pixel pp sums its list; 4 lanes x 4 channels per patch pixel, longest lists first
 #ifndef FB_NO_GATHER       // experiments (wrong results): -DFB_NO_GATHER, -DFB_NO_DOFF, -DFB_NO_DXATOMIC
             {
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(384) FB_WAVES void deform_dxoff_kernel(const float*
             }
 #endif
             FB_T(4);
-            if (mt + 1 < MT) FB_BARRIER();
+            if (mt + 1 < mt_end) FB_BARRIER();
             FB_T(5);
         }
     }
