@@ -69,9 +69,11 @@ constexpr int RB_MAXP = 7, RB_EXT = 192;
 template <int PP>
 __global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n_levels, int C, int batch, const float* __restrict__ rois, int P,
                                                                int min_level, int canonical_level, float canonical_size,
-                                                               const float* __restrict__ gout) {
+                                                               const float* __restrict__ gout, int split) {
     __shared__ float wy[RB_MAXP][RB_EXT], wx[RB_MAXP][RB_EXT];
-    const int r = blockIdx.x;
+    // `split` workgroups per ROI, each takes every split-th footprint column: the footprints of a training batch differ 50 x in area and the
+    // launch ends with its largest ROI
+    const int r = blockIdx.x / split, part = blockIdx.x - r * split;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* roi = rois + 5 * (size_t)r;
     const int b = (int)roi[0];
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n
     const int r1 = max(r0, min(H - 1, (int)floorf(rsh + roi_h) + 1)), c1 = max(c0, min(W - 1, (int)floorf(rsw + roi_w) + 1));
     const int nr = r1 - r0 + 1, nc = c1 - c0 + 1;
     if (PP == 0 || P != PP || nr > RB_EXT || nc > RB_EXT) {
-        roi_bwd_samples(grad, H, W, C, g0, P, rsh, rsw, bin_h, bin_w, gh, gw, count, lane, wave);
+        if (part == 0) roi_bwd_samples(grad, H, W, C, g0, P, rsh, rsw, bin_h, bin_w, gh, gw, count, lane, wave);
         return;
     }
     for (int i = threadIdx.x; i < RB_MAXP * RB_EXT; i += 256) { (&wy[0][0])[i] = 0.f; (&wx[0][0])[i] = 0.f; }
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n
         for (int ph = 0; ph < PP; ++ph)
 #pragma unroll
             for (int pw = 0; pw < PP; ++pw) g[ph][pw] = g0[((size_t)ph * PP + pw) * C + c] * inv_count;
-        for (int x = 0; x < nc; ++x) {
+        for (int x = part; x < nc; x += split) {
             float t[PP > 0 ? PP : 1];
 #pragma unroll
             for (int ph = 0; ph < PP; ++ph) t[ph] = 0.f;
@@ -431,12 +433,15 @@ int wd_roi_pool_fpn_bwd_f32(float* const* grad_feats, const int32_t* heights, co
     LevelsW lv;
     for (int i = 0; i < n_levels; ++i) { lv.grad[i] = grad_feats[i]; lv.h[i] = heights[i]; lv.w[i] = widths[i]; lv.scale[i] = scales[i]; }
     const char* mode = getenv("WD_ROI_BWD");                 // experiments: "sample" = 4 atomics per sample (the round-1 kernel)
+    int split = 4;
+    if (const char* e = getenv("WD_ROI_BWD_SPLIT")) split = atoi(e);
+    if (split < 1) split = 1;
     if (pooled == 7 && !(mode && strcmp(mode, "sample") == 0))
-        hipLaunchKernelGGL(roi_pool_fpn_bwd_kernel<7>, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels,
-                           batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out);
+        hipLaunchKernelGGL(roi_pool_fpn_bwd_kernel<7>, dim3((unsigned)(n_rois * split)), dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels,
+                           batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out, split);
     else
         hipLaunchKernelGGL(roi_pool_fpn_bwd_kernel<0>, dim3((unsigned)n_rois), dim3(256), 0, (hipStream_t)stream, lv, n_levels, channels,
-                           batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out);
+                           batch, rois, pooled, min_level, canonical_level, canonical_size, grad_out, 1);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
