@@ -59,6 +59,23 @@ int wd_gemm_nt_ws_f32(const float* A, const float* Bt, const float* bias, const 
 int wd_gemm_lt_f32(const float* a, const float* w, const float* bias, const float* residual, float* out, int m, int n, int k,
                    int relu, void* workspace, size_t workspace_bytes, void* stream);
 int wd_gemm_lt_plan_info(int m, int n, int k, int relu, int has_bias, int has_residual, float* best_us, int* candidates);
+/* fp32-equivalent GEMM on the bf16 matrix cores (csrc/det_gemm_split.hip): every f32 operand is carried EXACTLY as three bfloat16
+ * planes (hi + mid + lo by successive round-to-nearest subtraction), the six cross terms with i + j <= 2 run on
+ * v_mfma_f32_32x32x16_bf16 with f32 accumulation; error against float64 not above the exact-f32 kernels' (tests/test_gpu_gemm_split.py).
+ * Replaces the 1x1 convolutions of detectron2's BottleneckBlock (conv1 / conv3 / shortcut, job.log:534-546), the FPN lateral convs
+ * (job.log:1093-1108) and - wd_conv_split_f32 - the dense 3x3 convolutions of FPN output / RPN / box heads (job.log:1109-1160).
+ *   wd_gemm_split_pack_weight : w (N, K) f32 row-major -> `packed` (wd_gemm_split_packed_bytes(N, K) bytes, MFMA fragment order); once per weight.
+ *                               For a 3x3 convolution pass w as (N, 9 * C) with k = (kh * 3 + kw) * C + c.
+ *   wd_gemm_split_f32         : out (M, N) = relu?(a (M, K; row stride lda) . w^T + bias (N) + residual (M, N; row stride ldc)); residual may
+ *                               alias out.  K % 64 == 0, N % 32 == 0 (full speed: N % 256 == 0).
+ *   wd_conv_split_f32         : x (batch, H, W, C) NHWC, ksize 1 or 3, any stride / pad (zero padding), C % 64 == 0;
+ *                               out (batch, Ho, Wo, N) NHWC with the same fused epilogue. */
+size_t wd_gemm_split_packed_bytes(int N, int K);
+int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* stream);
+int wd_gemm_split_f32(const float* a, long lda, const void* packed_w, const float* bias, const float* residual, float* out, long ldc,
+                      int M, int N, int K, int relu, void* stream);
+int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void* packed_w, int ksize, int stride, int pad, const float* bias,
+                      const float* residual, float* out, int N, int relu, void* stream);
 /* wd_nms_sorted_f32 on n_seg (<= 8) independent row ranges in one pair of launches: detectron2's per-level batched_nms of the RPN
  * (find_top_rpn_proposals) with the levels' suppression chains in parallel workgroups.  Every range is sorted by descending
  * score; idxs may still mark rows that must not suppress (group -1).  n_keep: n_seg device ints. */

@@ -35,6 +35,7 @@ UNITS = {
     'det_gconv.hip': [],
     'det_gemm.hip': ['-munsafe-fp-atomics'],
     'det_gemm_lt.hip': [],
+    'det_gemm_split.hip': [],          # fp32-equivalent GEMM / 3x3 convolution on the bf16 matrix cores (exact 3-way operand split)
     'det_misc.hip': [],
     'det_preprocess.hip': ['-ffp-contract=off'],
     'jpeg_decode.hip': [],

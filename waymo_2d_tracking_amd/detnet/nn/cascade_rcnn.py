@@ -38,6 +38,31 @@ SCALE_CLAMP = math.log(1000.0 / 16)
 FUSED_TRAINING_EPILOGUES = True
 
 
+# Inference: 1x1 and dense 3x3 convolutions on the split-operand kernel (csrc/det_gemm_split.hip: f32 operands carried exactly as three bf16
+# planes, six cross terms on the bf16 matrix cores, f32 accumulation - error vs float64 below the f32 library GEMM's).  WD_SPLIT_GEMM=0 keeps
+# every convolution on the exact-f32 library path (hipBLASLt / MIOpen) - the "exact_f32" line of bench.py and the A/B parity tests.
+SPLIT_GEMM = os.environ.get('WD_SPLIT_GEMM', '1') != '0'
+
+
+def _split_ok(cin, cout):
+    return SPLIT_GEMM and cin % 64 == 0 and cout % 32 == 0
+
+
+class _PackedSplit:
+    """Per-module cache of a weight packed for the split-operand kernel (re-packed when the parameter changes or moves)."""
+
+    def __init__(self):
+        self.buf = None
+        self.key = None
+
+    def get(self, weight):
+        key = (weight.device, weight._version, weight.data_ptr())
+        if self.buf is None or self.key != key:
+            self.buf = ops.split_pack_weight(weight)
+            self.key = key
+        return self.buf
+
+
 def _msra(shape, gen, fan_out=True):
     w = torch.empty(shape)
     fan = shape[0] * shape[2] * shape[3] if fan_out else shape[1] * shape[2] * shape[3]
@@ -60,8 +85,24 @@ class Conv1x1(nn.Module):
         s = bn_scale / math.sqrt(1.0 + 1e-5) if not bias else 1.0
         self.weight = nn.Parameter(w * s, requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+        self._split = _PackedSplit()
 
     def forward(self, x, relu=False, residual=None, stride=1):
+        if not torch.is_grad_enabled() and x.is_cuda and _split_ok(self.weight.shape[1], self.weight.shape[0]):
+            # split-operand kernel: the strided shortcut reads its pixels in place (no gathered copy), the residual is added in the epilogue
+            # and the block output lands in the residual's buffer (dead after this block), as on the library path
+            pw = self._split.get(self.weight)
+            cout = self.weight.shape[0]
+            if stride != 1 or not x.is_contiguous(memory_format=torch.channels_last):
+                return ops.conv_split(x, pw, cout, 1, stride, 0, self.bias, residual, relu)
+            n, c, h, w = x.shape
+            a = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
+            r = None
+            if residual is not None:
+                r = residual if residual.is_contiguous(memory_format=torch.channels_last) else residual.contiguous(memory_format=torch.channels_last)
+                r = r.permute(0, 2, 3, 1).reshape(n * h * w, cout)
+            y = ops.gemm_split(a, pw, cout, self.bias, r, relu, out=r)
+            return y.view(n, h, w, cout).permute(0, 3, 1, 2)
         if stride != 1:
             x = x[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)
         n, c, h, w = x.shape
@@ -108,8 +149,14 @@ class ConvBN(nn.Module):
         self.weight = nn.Parameter((w * s).contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
         self.stride, self.pad, self.groups = stride, pad, groups
+        self._split = _PackedSplit()
 
     def forward(self, x, relu=False):
+        if (not torch.is_grad_enabled() and x.is_cuda and self.groups == 1 and self.weight.shape[2] in (1, 3)
+                and _split_ok(self.weight.shape[1], self.weight.shape[0])):
+            # dense 3x3 (FPN output convs, RPN conv): implicit GEMM over (tap, channel) on the split-operand kernel, bias + ReLU fused
+            return ops.conv_split(x, self._split.get(self.weight), self.weight.shape[0], self.weight.shape[2], self.stride, self.pad,
+                                  self.bias, None, relu)
         if not torch.is_grad_enabled() and self.weight.shape[0] % 4 == 0:
             # inference: bias (+ReLU) in one vectorised NHWC pass behind the library conv instead of the framework's
             # broadcast bias add (+ separate ReLU)
@@ -350,11 +397,15 @@ class BoxHead(nn.Module):
         self.cls_bias = nn.Parameter(torch.zeros(num_classes + 1), requires_grad=False)
         self.box_weight = nn.Parameter(torch.empty(4, 1024).normal_(0, 0.001, generator=gen), requires_grad=False)
         self.box_bias = nn.Parameter(torch.zeros(4), requires_grad=False)
+        self._split = [_PackedSplit() for _ in range(4)]
 
     def forward(self, x):
         train = torch.is_grad_enabled()
-        for conv, norm in zip(self.convs, self.norms):
-            x = conv(x)
+        for li, (conv, norm) in enumerate(zip(self.convs, self.norms)):
+            if not train and x.is_cuda and _split_ok(256, 256):
+                x = ops.conv_split(x, self._split[li].get(conv.weight), 256, 3, 1, 1)
+            else:
+                x = conv(x)
             if train:
                 if FUSED_TRAINING_EPILOGUES and x.shape[2] * x.shape[3] <= 64 and x.shape[0] > 0:
                     x = ops.GroupNormReluFn.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, True)

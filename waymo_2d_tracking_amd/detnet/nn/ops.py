@@ -323,6 +323,74 @@ def gemm_lt(a, weight, bias=None, residual=None, relu=False, out=None):
     return out
 
 
+def _split_log_begin():
+    if EVENT_LOG is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _split_log_end(e0, tag, m, n, k):
+    """bench.py instrumentation: HIP events around the launch on the launch stream; flops = the bf16 matrix-core flops actually issued
+    (six cross terms: 6 x 2 M N K), priced against the dense bf16 MFMA peak."""
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    EVENT_LOG.append((tag, 12.0 * m * n * k, e0, e1))
+
+
+def split_pack_weight(weight):
+    """(N, K) f32 GEMM weight, or an (N, C, 3, 3) / (N, C, 1, 1) convolution weight -> packed bf16 planes (hi, mid, lo) in MFMA fragment order
+    for gemm_split / conv_split (wd_gemm_split_pack_weight).  Convolution weights are laid out k = (kh * 3 + kw) * C + c."""
+    w = weight.detach().float()
+    if w.dim() == 4:
+        w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    w = w.contiguous()
+    n, k = w.shape
+    lib = _lib.lib()
+    nbytes = int(lib.wd_gemm_split_packed_bytes(C.c_int(n), C.c_int(k)))
+    if nbytes == 0:
+        raise ValueError('split_pack_weight: K must be a multiple of 64 (N=%d K=%d)' % (n, k))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.wd_gemm_split_pack_weight(_p(w), C.c_int(n), C.c_int(k), _p(packed), _stream()), 'wd_gemm_split_pack_weight')
+    return packed
+
+
+def gemm_split(a, packed, n, bias=None, residual=None, relu=False, out=None):
+    """out (M, N) = relu?(a (M, K) @ W.T + bias + residual) with W packed by split_pack_weight: f32 operands as exact 3 x bf16 splits, six
+    cross terms on the bf16 matrix cores, f32 accumulation (wd_gemm_split_f32).  `a` may be a row-strided view; residual may be `out`."""
+    m, k = a.shape
+    assert a.dtype == torch.float32 and a.stride(1) == 1
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    assert out.is_contiguous() and (residual is None or residual.is_contiguous())
+    ev = _split_log_begin()
+    _lib.check(_lib.lib().wd_gemm_split_f32(_p(a), C.c_long(a.stride(0)), _p(packed), _p(bias), _p(residual), _p(out), C.c_long(n), C.c_int(m),
+                                            C.c_int(n), C.c_int(k), C.c_int(1 if relu else 0), _stream()), 'wd_gemm_split_f32')
+    _split_log_end(ev, 'gemm_split_kernel: 1x1 conv / GEMM M=%d N=%d K=%d' % (m, n, k), m, n, k)
+    return out
+
+
+def conv_split(x, packed, n_out, ksize, stride=1, pad=0, bias=None, residual=None, relu=False):
+    """Dense ksize x ksize convolution (1 or 3) of an (N, C, H, W) channels_last map as an implicit GEMM on the split-operand kernel
+    (wd_conv_split_f32); returns (N, n_out, Ho, Wo) channels_last.  residual: (N, n_out, Ho, Wo) channels_last or None."""
+    x = _nhwc(x)
+    b, c, h, w = x.shape
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    out = torch.empty((b, n_out, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None:
+        residual = _nhwc(residual)
+    ev = _split_log_begin()
+    _lib.check(_lib.lib().wd_conv_split_f32(_p(x), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(c), _p(packed), C.c_int(ksize), C.c_int(stride),
+                                            C.c_int(pad), _p(bias), _p(residual), _p(out), C.c_int(n_out), C.c_int(1 if relu else 0), _stream()),
+               'wd_conv_split_f32')
+    _split_log_end(ev, 'gemm_split_kernel: %dx%d conv s%d M=%d N=%d K=%d' % (ksize, ksize, stride, b * ho * wo, n_out, ksize * ksize * c), b * ho * wo, n_out,
+                   ksize * ksize * c)
+    return out
+
+
 SCALE_CLAMP = 4.135166556742356          # log(1000 / 16), Box2BoxTransform
 
 
