@@ -48,7 +48,7 @@ def parse_args():
                          '(always on when N > 1 or WT_FORCE_DIST=1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--inflight', type=int, default=1,
-                    help='e2e/detect: frames in flight (hipGraph lanes on separate streams); EXPERIMENT: 2 deadlocks at 1920x1280 (spin-waiting library kernels)')
+                    help='e2e/detect: frames in flight (hipGraph lanes on separate streams); > 1 is refused unless WT_EXPERIMENT=1 (deadlocks at 1920x1280)')
     ap.add_argument('--auto-contrast', action='store_true', help='e2e/detect: ImageOps.autocontrast on every frame (the --auto-contrast=1 of the '
                     "reference's documented TTA run, README.md:37)")
     ap.add_argument('--from-jpeg', action='store_true', help='e2e/detect: the frames enter as JPEG bytes and are decoded on the GPU inside the step '
@@ -58,6 +58,13 @@ def parse_args():
     ap.add_argument('--no-graph', action='store_true', help='e2e/detect: launch every frame eagerly instead of replaying the captured hipGraph')
     ap.add_argument('--no-verify', action='store_true', help='skip the oracle replay of the timed output (after the timed region)')
     return ap.parse_args()
+
+
+def check_flags(args):
+    """--inflight > 1 deadlocks at 1920x1280 (two hipGraph lanes whose library kernels spin-wait on each other): an experiment, refused unless
+    WT_EXPERIMENT=1 says the caller knows."""
+    if args.inflight > 1 and os.environ.get('WT_EXPERIMENT') != '1':
+        raise SystemExit('bench.py: --inflight %d is an experiment that deadlocks at full size; set WT_EXPERIMENT=1 to run it anyway' % args.inflight)
 
 
 def launch_if_needed(args):
@@ -242,13 +249,14 @@ def stage_track(args, world, rank):
                                        and np.array_equal(out['frame'], ref['frame']) and np.array_equal(out['bbox'], ref['bbox'])),
                                rows=rows, rows_ref=int(len(ref['frame'])), against='oracle/sort_oracle.c on the same detections')
     if rank == 0 and world == 1 and not args.no_cpu_baseline:       # the CPU baseline is timed at N = 1 only
-        res['cpu_baseline'] = cpu_baseline_track(ithr, sthr)
+        res['cpu_baseline'] = cpu_baseline_track(ithr, sthr, args.segments)
     return res, steps, warmup
 
 
-def cpu_baseline_track(ithr, sthr):
-    """The C oracle on the host cores: one thread, then one thread per core with the segments spread over the threads
-    (streams are independent apart from the id offsets, exactly like the GPU sharding) - SURVEY 8d (ii)."""
+def cpu_baseline_track(ithr, sthr, segments=1):
+    """The C oracle on the host cores - SURVEY 8d (ii).  `value` is the SAME configuration as the GPU line (`segments` segments, i.e.
+    5 x segments independent camera streams, one host thread per stream up to the core count); the single-thread rate, the one-segment rate
+    and the all-cores rate (one segment per thread, 128 segments) ride along as side keys."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build()
@@ -283,7 +291,24 @@ def cpu_baseline_track(ithr, sthr):
     with ThreadPoolExecutor(len(subs)) as ex:
         list(ex.map(one_stream, subs))
     dt1 = time.perf_counter() - t0
-    res = dict(value=n_thr * per_thread * 990 / dtm, unit='frames/s', cores=n_thr, kind='port',
+    # the GPU line's own configuration: `segments` segments = 5 x segments independent streams, one thread per stream
+    if segments == 1:
+        same_value, same_threads = reps1 * 990 / dt1, len(subs)
+    else:
+        n_streams = 5 * segments
+        thr_s = min(n_streams, cores)
+        jobs = [subs[i % len(subs)] for i in range(n_streams)]
+
+        def stream_job(sp):
+            for _ in range(reps1):
+                O.track_streams(sp, 2, 0, sthr, ithr)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(thr_s) as ex:
+            list(ex.map(stream_job, jobs))
+        same_value, same_threads = reps1 * 198 * n_streams / (time.perf_counter() - t0), thr_s
+    res = dict(value=same_value, unit='frames/s', cores=same_threads, kind='port',
+               same_config='%d segment(s) x 5 camera streams, one thread per stream (%d threads)' % (segments, same_threads),
+               all_cores_one_segment_per_thread=dict(value=n_thr * per_thread * 990 / dtm, threads=n_thr),
                single_thread=single, one_segment_one_thread_per_stream=dict(value=reps1 * 990 / dt1, threads=len(subs)),
                sample='oracle/sort_oracle.c (C restatement of tracking/sort): 1 segment x 5 cameras x 198 frames per '
                       'call; %d calls on one thread (%.0f frames/s), then %d threads x %d calls (one segment per thread, '
@@ -416,6 +441,7 @@ def cpu_baseline_e2e(pipe, track, height=448, width=640):
     # measured once at the real size (tools/cpu_baseline_full.py, committed): how good the pixel-ratio extrapolation is; and the
     # reference's OWN Python SORT loop on the restated filterpy / sklearn stubs (oracle/time_reference_sort.py)
     here = os.path.dirname(os.path.abspath(__file__))
+    res['small_sample'] = dict(value=res['value'], size='%dx%d' % (width, height))
     for name, key in (('r04_cpu_baseline_full_size.json', 'measured_full_size'), ('r02_reference_sort_on_stub.json', 'reference_python_sort')):
         path = os.path.join(here, 'profiles', name)
         if os.path.exists(path):
@@ -426,6 +452,16 @@ def cpu_baseline_e2e(pipe, track, height=448, width=640):
             if key == 'measured_full_size' and '1920x1280' in d:
                 res[key] = dict(frames_per_s=d['1920x1280']['frames_per_s'], detector_s=d['1920x1280']['detector_s'], threads=d.get('threads'),
                                 time_ratio_full_over_640x448=d.get('measured_time_ratio_full_over_small'), source='profiles/' + name)
+                # `value` = the like-for-like figure: one WHOLE 1920x1280 frame through the same CPU port takes 68 s on these cores - beyond the
+                # bounded sample a default bench run may spend - so it was measured once on the GPU box (tools/cpu_baseline_full.py, committed
+                # profile) and is re-scaled here by what THIS run's live 640x448 sample says about this box (live small / recorded small)
+                small_rec = d.get('640x448', {}).get('frames_per_s')
+                calib = (res['small_sample']['value'] / small_rec) if small_rec else 1.0
+                res['value'] = d['1920x1280']['frames_per_s'] * calib
+                res['sample'] = ('1920x1280 frame through oracle/detector_ref.py (PyTorch CPU fp32, same parameters) + oracle SORT: %.1f s per frame measured at '
+                                 'full size on the GPU box (profiles/%s, %s threads), scaled by this run\'s live 640x448 sample (%.3f frames/s now vs %.3f '
+                                 'recorded: x%.2f); ' % (d['1920x1280']['detector_s'], name, d.get('threads'), res['small_sample']['value'], small_rec or 0.0, calib)
+                                 + res['sample'])
             elif key == 'reference_python_sort':
                 res[key] = dict(d, source='profiles/' + name) if isinstance(d, dict) else d
     return res
@@ -544,6 +580,7 @@ def stage_decode(args, world, rank):
 
 def main():
     args = parse_args()
+    check_flags(args)
     launch_if_needed(args)         # no GPU call before this line
     import torch
     if not torch.cuda.is_available():

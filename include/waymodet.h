@@ -76,6 +76,8 @@ int wd_gemm_split_f32(const float* a, long lda, const void* packed_w, const floa
                       int M, int N, int K, int relu, void* stream);
 int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void* packed_w, int ksize, int stride, int pad, const float* bias,
                       const float* residual, float* out, int N, int relu, void* stream);
+/* diagnostics: per-workgroup s_memtime stamps of the following wd_gemm_split_f32 / wd_conv_split_f32 launches (8 int64 per workgroup; NULL = off) */
+int wd_gemm_split_debug_stamps(long long* buf);
 /* wd_nms_sorted_f32 on n_seg (<= 8) independent row ranges in one pair of launches: detectron2's per-level batched_nms of the RPN
  * (find_top_rpn_proposals) with the levels' suppression chains in parallel workgroups.  Every range is sorted by descending
  * score; idxs may still mark rows that must not suppress (group -1).  n_keep: n_seg device ints. */

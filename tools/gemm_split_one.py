@@ -18,13 +18,26 @@ bias = torch.randn(n, device='cuda')
 res = torch.randn(m, n, device='cuda')
 pw = ops.split_pack_weight(w)
 out = torch.empty(m, n, device='cuda')
-for _ in range(iters):
+def run():
     ops.gemm_split(a, pw, n, bias if epi else None, res if epi else None, bool(epi), out=out)
+
+
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+# the launches are replayed from a captured hipGraph (as in the pipeline): an eager python loop adds ~20 us of launch gap per call
+g = torch.cuda.CUDAGraph()
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):
+    run()
+    with torch.cuda.graph(g, stream=st):
+        for _ in range(iters):
+            run()
+g.replay()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(iters):
-    ops.gemm_split(a, pw, n, bias if epi else None, res if epi else None, bool(epi), out=out)
+g.replay()
 e1.record()
 torch.cuda.synchronize()
-print('gemm_split %dx%dx%d epi=%d: %.1f us' % (m, n, k, epi, e0.elapsed_time(e1) / iters * 1e3))
+print('gemm_split %dx%dx%d epi=%d: %.1f us per launch (graph replay of %d)' % (m, n, k, epi, e0.elapsed_time(e1) / iters * 1e3, iters))

@@ -499,6 +499,35 @@ def _pmc_traffic(tag):
     return None
 
 
+def exact_f32_line(args, rank, track, fps, steps):
+    """The all-exact-f32 configuration (every convolution on the f32 library / f32-MFMA path, WD_SPLIT_GEMM=0) timed in the SAME invocation on
+    a second pipeline: the secondary line the round-4 review asked to carry next to the split-operand headline."""
+    import time
+    from .detnet.nn import cascade_rcnn
+    cascade_rcnn.SPLIT_GEMM = False
+    try:
+        pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False),
+                                   defer_tracking=track and not getattr(args, 'no_defer_track', False), auto_contrast=getattr(args, 'auto_contrast', False))
+        if pipe.use_graph:
+            pipe._capture()
+        pipe.step(track)
+        pipe.flush()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.step(track)
+        pipe.flush()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = dict(value=pipe.n_frames * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, steps=steps, warmup=1,
+                   note='same pipeline with WD_SPLIT_GEMM=0: 1x1 convolutions on hipBLASLt f32, dense 3x3 on MIOpen f32')
+        del pipe
+    finally:
+        cascade_rcnn.SPLIT_GEMM = True
+    torch.cuda.empty_cache()
+    return out
+
+
 def run(args, world, rank, timed_steps):
     from .detnet.nn import ops
     fps = max(1, args.frames_per_step // 5)
@@ -593,6 +622,8 @@ def run(args, world, rank, timed_steps):
         roofline['timing_note'] = ('avg_us: HIP events on the launch stream around every launch of the LAST frame of each timed step, which runs eagerly '
                                    '(the other frames replay the captured hipGraph of the same launches and share the chip with the SORT kernel of the '
                                    'previous chunk); rocprofv3 --kernel-trace of the same command agrees (profiles/)')
+    from .detnet.nn import cascade_rcnn
+    split_on = cascade_rcnn.SPLIT_GEMM
     res = dict(value=frames * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, dtype='f32',
                workload='Cascade R-CNN X152-32x8d-FPN dconv (random-init, fp32, batch 1%s) on synthetic 1920x1280x3 frames'
                         ' -> top-100 detections/frame -> %s; %d cameras x %d frames per step per GPU'
@@ -600,6 +631,12 @@ def run(args, world, rank, timed_steps):
                            'SORT (max_age 2, min_hits 0, all boxes tracked; trackers resident for the whole segment)' if track else 'no tracking', 5, fps),
                roofline=roofline,
                extra=dict(frames_per_step=frames, dets_per_frame=pipe.n_dets_total / max(1, frames * state['n']), hip_graph=pipe._graph is not None, track_rows=n_out, births=births))
+    if split_on:
+        res['workload'] += ('; 1x1 and dense 3x3 convolutions: f32 operands as exact 3 x bf16 splits, six cross terms on the bf16 matrix cores, f32 accumulate '
+                            '(csrc/det_gemm_split.hip; error vs float64 below the f32 library GEMM\'s, profiles/r05_split_gemm_error.txt), everything else fp32')
+        res['extra']['split_gemm'] = True
+        if world == 1 and os.environ.get('WT_BENCH_NO_EXACT') != '1':
+            res['extra']['exact_f32'] = exact_f32_line(args, rank, track, fps, min(steps, 3))
     if pipe.jpeg is not None:
         import io
         from PIL import Image

@@ -32,6 +32,7 @@
 #include "common.h"
 #include "../../include/waymodet.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -53,6 +54,7 @@ struct SplitArgs {
     long lda, ldc;                // row strides (floats) of a (plain mode) and of out / residual
     int M, N, K, relu;
     int tiles_m, tiles_n, xmap;
+    long long* stamps;            // debug: per-workgroup s_memtime stamps (start, main loop, epilogue, end) or nullptr
     // convolution mode: a = NHWC (batch, H, W, C); output pixel grid (Ho, Wo); K = taps * C
     int H, W, C, Ho, Wo, stride, pad, ksize;
 };
@@ -71,9 +73,51 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
     l = pk_bf16(s0, s1);
 }
 
+// ---- epilogue (both kernels) ----
+// C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane owns ONE column.  The tile goes
+// through LDS (free after the main loop's last barrier) so that global memory sees whole 1-KiB output rows: per pass up to 3 row blocks
+// (96 rows x 256 floats); every wave writes its 32-column strip, then reads whole rows as float4 per lane and adds bias / residual / ReLU.
+template <int MT>
+__device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char* smem, const f32x16 (&acc)[MT], int m0, int n0, int wave, int lane) {
+    const int rr = lane & 31, rg = lane >> 5;
+    float* ct = reinterpret_cast<float*>(smem);
+    const int ncols = p.N - n0 < BN ? p.N - n0 : BN;            // valid columns of this tile (multiple of 32)
+    const int c4 = 4 * lane;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && c4 < ncols) bv = *reinterpret_cast<const float4*>(p.bias + n0 + c4);
+#pragma unroll
+    for (int i0 = 0; i0 < MT; i0 += 3) {
+        constexpr int PASS = 3;
+        if (i0 > 0) __builtin_amdgcn_s_barrier();              // the previous pass has been read
+#pragma unroll
+        for (int i = i0; i < i0 + PASS && i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                ct[((i - i0) * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg) * BN + 32 * wave + rr] = acc[i][e];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        const int nrows = 32 * ((MT - i0) < PASS ? (MT - i0) : PASS);
+#pragma unroll 4
+        for (int r = wave; r < nrows; r += 8) {
+            const int row = m0 + 32 * i0 + r;
+            if (row < p.M && c4 < ncols) {
+                float4 v = *reinterpret_cast<const float4*>(ct + r * BN + c4);
+                const size_t o = (size_t)row * p.ldc + n0 + c4;
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.residual) {
+                    const float4 q = *reinterpret_cast<const float4*>(p.residual + o);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(p.out + o) = v;
+            }
+        }
+    }
+}
+
 // MODE 0: plain row-major A.  MODE 1: NHWC convolution source (ksize 1 or 3, any stride / pad).
 template <int MT, int MODE>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_split_k64_kernel(const SplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = 32 * MT;
     constexpr int PLANE = BM * 128;              // bytes of one bf16 plane of a K step
@@ -236,29 +280,248 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #undef MF
 #undef RD
 
-    // ---- epilogue ----
-    // C/D layout of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane owns ONE column.  The tile goes
-    // through LDS (free now) so that global memory sees whole 1-KiB output rows: per pass up to 3 row blocks (96 rows x 256 floats); every
-    // wave writes its 32-column strip, then reads whole rows as float4 per lane and adds bias / residual / ReLU on the way out.
+    split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane);
+}
+
+// ---- round 5, second structure: K steps of 32 through a ring of THREE LDS buffers -------------------------------------------------
+// Same tile, same fragment order, same split; what changes is the hand-off.  The K-64 kernel above double-buffers: the buffer a K step
+// reads is written during the step before, so the first fragments of a K step can only be requested behind the barrier and every wave's
+// matrix pipe drains once per K step (counters: 25 % of the main loop's wave cycles).  Here step j reads buffer j % 3 while the split of
+// step j + 2 is written into buffer (j + 2) % 3 - which nobody has touched since the barrier of step j - 1 - so buffer (j + 1) % 3 is
+// complete and visible for the whole of step j: the last slots of a step prefetch the next step's fragments ACROSS the barrier, whose
+// wait is a counted lgkmcnt (the LDS writes are older than the MT outstanding prefetch reads).  One barrier per 2 x 6 MT MFMAs, no drain.
+// A rows are staged as float2 per thread (160 rows x 32 floats / 512 threads = 5 float2), three ds_write_b32 per row block.
+template <int MT, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 32 * MT;
+    constexpr int PLANE = BM * 64;               // bytes of one bf16 plane of a 32-deep K step
+    constexpr int BUF = 3 * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        if (j >= q + (x < r ? 1 : 0)) return;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    long long t_start = 0, r_start = 0;
+    if (p.stamps) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
+    int tm, tn;
+    if (p.xmap == 0) { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; } else { tn = id / p.tiles_m; tm = id - tn * p.tiles_m; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.K / 32;
+
+    // ---- A staging: thread -> (row srow + 32 i, float2 sk2 of the 32-float K step) ----
+    const int srow = tid >> 4, sk2 = tid & 15;
+    int aoff[MT];
+    unsigned vmask[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = m0 + srow + 32 * i;
+        m = m < p.M ? m : p.M - 1;
+        if (MODE == 0) {
+            aoff[i] = (int)(m * p.lda) + 2 * sk2;
+            vmask[i] = 1u;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, rem = m - b * hw;
+            const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+            const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;
+            aoff[i] = ((b * p.H + y0) * p.W + x0) * p.C + 2 * sk2;
+            unsigned vm = 0;
+            for (int t = 0; t < p.ksize * p.ksize; ++t) {
+                const int yy = y0 + t / p.ksize, xx = x0 + t % p.ksize;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) vm |= 1u << t;
+            }
+            vmask[i] = vm;
+        }
+    }
+    const int kc = (MODE == 1) ? p.C / 32 : 1;    // K steps per tap
+    float2 araw[MT];
+    auto a_load_row = [&](int kt, int i) {          // row block i of K step kt (clamped) -> araw[i]
+        kt = kt < nk ? kt : nk - 1;
+        if (MODE == 0) {
+            araw[i] = *reinterpret_cast<const float2*>(p.a + (aoff[i] + kt * 32));
+        } else {
+            const int tap = kt / kc, cb = kt - tap * kc;
+            const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
+            const int delta = (dy * p.W + dx) * p.C + cb * 32;
+            const bool ok = ((vmask[i] >> tap) & 1u) != 0;
+            const int off = ok ? aoff[i] + delta : 2 * sk2;               // always a valid address; zeroed below
+            const float2 v = *reinterpret_cast<const float2*>(p.a + off);
+            araw[i] = ok ? v : make_float2(0.f, 0.f);
+        }
+    };
+    const int wofs = srow * 64 + ((((sk2 >> 2) ^ ((srow >> 2) & 3))) << 4) + ((sk2 & 3) << 2);
+    auto a_store_row = [&](int bufoff, int i) {     // split row block i of araw and write its three planes (one bf16 pair each)
+        unsigned char* base = smem + bufoff + wofs + i * 2048;
+        unsigned h, m, l;
+        split_pair(araw[i].x, araw[i].y, h, m, l);
+        *reinterpret_cast<unsigned*>(base) = h;
+        *reinterpret_cast<unsigned*>(base + PLANE) = m;
+        *reinterpret_cast<unsigned*>(base + 2 * PLANE) = l;
+    };
+
+    // ---- W fragments: this wave's 32 columns, [K / 16][3 planes][64 lanes] uint4; one K step (two sub-steps) in registers ----
+    const int nt32 = (n0 >> 5) + wave;
+    const bool active = nt32 * 32 < p.N;          // waves past N (N % 256 != 0) compute on tile 0 and store nothing
+    const uint4* wbase = p.w + (size_t)(active ? nt32 : 0) * (size_t)(p.K / 16) * 192 + lane;
+    const int nsub = nk * 2;
+    bf16x8 wf[2][3];
+    auto w_load = [&](int sub, int slot) {
+        sub = sub < nsub ? sub : nsub - 1;
+        const uint4* q = wbase + (size_t)sub * 192;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wf[slot][pl] = __builtin_bit_cast(bf16x8, q[pl * 64]);
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // fragment read offsets: lane (row rr, k half rg), sub-step s -> 16-byte slot (2 s + rg) ^ ((rr >> 2) & 3) of the 64-byte row
+    const int rr = lane & 31, rg = lane >> 5;
+    const int rofs0 = rr * 64 + ((((0 + rg) ^ ((rr >> 2) & 3))) << 4);
+    const int rofs1 = rr * 64 + ((((2 + rg) ^ ((rr >> 2) & 3))) << 4);
+
+    // ---- prologue: K steps 0 and 1 into buffers 0 and 1, step 2 in registers ----
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_load_row(0, i);
+    w_load(0, 0);
+    w_load(1, 1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { a_store_row(0, i); a_load_row(1, i); }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { a_store_row(BUF, i); a_load_row(2, i); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 af[MT][3];
+#define SB __builtin_amdgcn_sched_barrier(0)
+    // compile-time ablations for tools/split_ablation.sh (timing only, results wrong): WD_ABL bit 0 no A global loads, 1 no split / LDS
+    // writes, 2 no W loads, 3 no barrier, 4 no MFMAs, 5 no fragment reads
+#ifndef WD_ABL
+#define WD_ABL 0
+#endif
+#if WD_ABL & 16
+#define MF(pa, pb, slot)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(af[i][pa]), "v"(wf[slot][pb]));
+#else
+#define MF(pa, pb, slot)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], wf[slot][pb], acc[i], 0, 0, 0);
+#endif
+#if WD_ABL & 32
+#define RD(addr, pl)
+#else
+#define RD(addr, pl)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
+        af[i][pl] = *reinterpret_cast<const bf16x8*>(smem + (addr) + (pl) * PLANE + i * 2048);
+#endif
+#if WD_ABL & 2
+#define SPLIT_ROW(i_)
+#elif WD_ABL & 1
+#define SPLIT_ROW(i_)                                                                                         \
+    if ((i_) < MT) { a_store_row(wr, (i_)); }
+#else
+#define SPLIT_ROW(i_)                                                                                         \
+    if ((i_) < MT) { a_store_row(wr, (i_)); a_load_row(kt + 3, (i_)); }
+#endif
+#if WD_ABL & 4
+#define WLOAD(sub, slot)
+#else
+#define WLOAD(sub, slot) w_load(sub, slot);
+#endif
+    RD(rofs0, 2) RD(rofs0, 1) RD(rofs0, 0)
+    SB;
+    long long t_main = 0;
+    if (p.stamps) t_main = __builtin_amdgcn_s_memtime();
+    int cur = 0, nxt = BUF, wr = 2 * BUF;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int a1 = cur + rofs1, a0n = nxt + rofs0;
+        // sub-step 0 (fragments in registers); its slots request sub-step 1's fragments of the same buffer
+        MF(2, 0, 0) RD(a1, 2) SB;
+        MF(1, 1, 0) SPLIT_ROW(0) SB;
+        MF(1, 0, 0) RD(a1, 1) SB;
+        MF(0, 2, 0) SPLIT_ROW(1) SB;
+        MF(0, 1, 0) SPLIT_ROW(2) SB;
+        MF(0, 0, 0) RD(a1, 0) WLOAD(2 * kt + 2, 0) SB;
+        // sub-step 1; its slots request sub-step 0 of the NEXT K step's buffer (complete since the previous barrier)
+        MF(2, 0, 1) RD(a0n, 2) SB;
+        MF(1, 1, 1) SPLIT_ROW(3) SB;
+        MF(1, 0, 1) RD(a0n, 1) SB;
+        MF(0, 2, 1) SPLIT_ROW(4) SB;
+        MF(0, 1, 1) SPLIT_ROW(5) SB;
+        MF(0, 0, 1) RD(a0n, 0) WLOAD(2 * kt + 3, 1) SB;
+        // this wave's LDS writes (older than the MT prefetch reads just issued) are done; the prefetch stays in flight across the barrier
+#if !(WD_ABL & 8)
+        __builtin_amdgcn_s_waitcnt(0xC07F | (MT << 8));
+        __builtin_amdgcn_s_barrier();
+#endif
+        SB;
+        const int t = cur; cur = nxt; nxt = wr; wr = t;
+    }
+#undef SB
+#undef MF
+#undef RD
+#undef SPLIT_ROW
+#undef WLOAD
+    long long t_epi = 0;
+    if (p.stamps) t_epi = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // the dangling prefetch of the step behind the last one
+    __builtin_amdgcn_s_barrier();
+    split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane);
+    if (p.stamps && tid == 0) {
+        long long* o = p.stamps + 8 * (long)blockIdx.x;
+        o[0] = t_start; o[1] = t_main; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = id; o[5] = __builtin_amdgcn_s_getreg(20 /* XCC_ID */ | (0 << 6) | (3 << 11));
+        o[6] = r_start; o[7] = __builtin_amdgcn_s_memrealtime();            // constant 100 MHz clock, common to the chip
+    }
+}
+
+// ---- round 5, third structure: FOUR waves (one per SIMD, up to 512 registers each), wave tile (32 MT) x 64 ------------------------------
+// The ring of the kernel above, but a wave owns TWO 32-column tiles: every A fragment read from LDS feeds 4 MFMAs instead of 2 (half the
+// ds_read traffic per MFMA - the ablations priced the fragment reads at 16 % of the kernel), and with the whole register file of a SIMD to
+// itself the wave can afford a SECOND accumulator set: DUAL = the five small cross terms accumulate apart from hi.hi, so the large
+// accumulator is rounded 2 K / 16 times instead of 12 K / 16 (error against float64 ~ 1/3 of an f32 fmaf chain's); the two sets are added in
+// the epilogue.  Everything is software-pipelined inside the one wave (fragment reads >= 3 slots of 2 MT MFMAs ahead, W fragments and A rows
+// a whole K step ahead), so no second wave is needed to hide latency.  A rows are staged as float4 per thread (256 threads: 8 x 16 bytes per
+// 32-float row, 5 row blocks), three ds_write_b64 per row block.
+constexpr int W4_THREADS = 256;
+
+template <int MT, bool DUAL>
+__device__ __forceinline__ void split_epilogue_w4(const SplitArgs& p, unsigned char* smem, f32x16 (&acc)[2][MT], const f32x16 (&accs)[2][DUAL ? MT : 1], int m0, int n0,
+                                                  int wave, int lane) {
+    const int rr = lane & 31, rg = lane >> 5;
     float* ct = reinterpret_cast<float*>(smem);
-    const int ncols = p.N - n0 < BN ? p.N - n0 : BN;            // valid columns of this tile (multiple of 32)
+    const int ncols = p.N - n0 < BN ? p.N - n0 : BN;
     const int c4 = 4 * lane;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && c4 < ncols) bv = *reinterpret_cast<const float4*>(p.bias + n0 + c4);
 #pragma unroll
     for (int i0 = 0; i0 < MT; i0 += 3) {
         constexpr int PASS = 3;
-        if (i0 > 0) __builtin_amdgcn_s_barrier();              // the previous pass has been read
+        if (i0 > 0) __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = i0; i < i0 + PASS && i < MT; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                ct[((i - i0) * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg) * BN + 32 * wave + rr] = acc[i][e];
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[c][i][e];
+                    if (DUAL) v += accs[c][DUAL ? i : 0][e];
+                    ct[((i - i0) * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg) * BN + 64 * wave + 32 * c + rr] = v;
+                }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
         const int nrows = 32 * ((MT - i0) < PASS ? (MT - i0) : PASS);
 #pragma unroll 4
-        for (int r = wave; r < nrows; r += 8) {
+        for (int r = wave; r < nrows; r += 4) {
             const int row = m0 + 32 * i0 + r;
             if (row < p.M && c4 < ncols) {
                 float4 v = *reinterpret_cast<const float4*>(ct + r * BN + c4);
@@ -272,6 +535,184 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
                 *reinterpret_cast<float4*>(p.out + o) = v;
             }
         }
+    }
+}
+
+template <int MT, int MODE, bool DUAL>
+__global__ __launch_bounds__(W4_THREADS, 1) void gemm_split_w4_kernel(const SplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 32 * MT;
+    constexpr int PLANE = BM * 64;
+    constexpr int BUF = 3 * PLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = p.tiles_m * p.tiles_n;
+    int id;
+    {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        if (j >= q + (x < r ? 1 : 0)) return;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    long long t_start = 0, r_start = 0;
+    if (p.stamps) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
+    int tm, tn;
+    if (p.xmap == 0) { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; } else { tn = id / p.tiles_m; tm = id - tn * p.tiles_m; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.K / 32;
+
+    // ---- A staging: thread -> (row srow + 32 i, float4 sk4 of the 32-float K step) ----
+    const int srow = tid >> 3, sk4 = tid & 7;
+    unsigned aoff[MT];                            // element offset of the thread's float4 at K step 0 (MODE 1: tap (0, 0), channel 0; may wrap below 0)
+    unsigned vmask[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = m0 + srow + 32 * i;
+        m = m < p.M ? m : p.M - 1;
+        if (MODE == 0) {
+            aoff[i] = (unsigned)(m * p.lda) + 4u * sk4;
+            vmask[i] = 1u;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, rem = m - b * hw;
+            const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+            const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;
+            aoff[i] = (unsigned)(((b * p.H + y0) * p.W + x0) * p.C + 4 * sk4);
+            unsigned vm = 0;
+            for (int t = 0; t < p.ksize * p.ksize; ++t) {
+                const int yy = y0 + t / p.ksize, xx = x0 + t % p.ksize;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) vm |= 1u << t;
+            }
+            vmask[i] = vm;
+        }
+    }
+    const int kc = (MODE == 1) ? p.C / 32 : 1;
+    float4 araw[MT];
+    auto a_load_row = [&](int kt, int i) {
+        kt = kt < nk ? kt : nk - 1;
+        if (MODE == 0) {
+            araw[i] = *reinterpret_cast<const float4*>(p.a + (size_t)(aoff[i] + (unsigned)(kt * 32)));       // scalar base + 32-bit offset
+        } else {
+            const int tap = kt / kc, cb = kt - tap * kc;
+            const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
+            const unsigned delta = (unsigned)((dy * p.W + dx) * p.C + cb * 32);
+            const bool ok = ((vmask[i] >> tap) & 1u) != 0;
+            const unsigned off = ok ? aoff[i] + delta : 4u * sk4;
+            const float4 v = *reinterpret_cast<const float4*>(p.a + (size_t)off);
+            araw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int wofs = srow * 64 + ((((sk4 >> 1) ^ ((srow >> 2) & 3))) << 4) + ((sk4 & 1) << 3);
+    auto a_store_row = [&](int bufoff, int i) {
+        unsigned char* base = smem + bufoff + wofs + i * 2048;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split_pair(araw[i].x, araw[i].y, h0, m0_, l0);
+        split_pair(araw[i].z, araw[i].w, h1, m1, l1);
+        *reinterpret_cast<uint2*>(base) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(base + PLANE) = make_uint2(m0_, m1);
+        *reinterpret_cast<uint2*>(base + 2 * PLANE) = make_uint2(l0, l1);
+    };
+
+    // ---- W fragments: this wave's two 32-column tiles ----
+    const int nt32 = (n0 >> 5) + 2 * wave;
+    const int ntiles = p.N >> 5;
+    const size_t wstride = (size_t)(p.K / 16) * 192;
+    const uint4* wbase0 = p.w + (size_t)(nt32 < ntiles ? nt32 : 0) * wstride + lane;
+    const uint4* wbase1 = p.w + (size_t)(nt32 + 1 < ntiles ? nt32 + 1 : 0) * wstride + lane;
+    const int nsub = nk * 2;
+    bf16x8 wf[2][2][3];
+    auto w_load = [&](int sub, int slot) {
+        sub = sub < nsub ? sub : nsub - 1;
+        const uint4* q0 = wbase0 + (size_t)sub * 192;
+        const uint4* q1 = wbase1 + (size_t)sub * 192;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            wf[slot][0][pl] = __builtin_bit_cast(bf16x8, q0[pl * 64]);
+            wf[slot][1][pl] = __builtin_bit_cast(bf16x8, q1[pl * 64]);
+        }
+    };
+
+    f32x16 acc[2][MT], accs[2][DUAL ? MT : 1];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[c][i][e] = 0.f;
+                if (DUAL) accs[c][DUAL ? i : 0][e] = 0.f;
+            }
+
+    const int rr = lane & 31, rg = lane >> 5;
+    const int rofs0 = rr * 64 + ((((0 + rg) ^ ((rr >> 2) & 3))) << 4);
+    const int rofs1 = rr * 64 + ((((2 + rg) ^ ((rr >> 2) & 3))) << 4);
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_load_row(0, i);
+    w_load(0, 0);
+    w_load(1, 1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { a_store_row(0, i); a_load_row(1, i); }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { a_store_row(BUF, i); a_load_row(2, i); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 af[MT][3];
+#define SB __builtin_amdgcn_sched_barrier(0)
+    // MFS: a small cross term (goes to the second accumulator set under DUAL); MFH: hi.hi
+#define MFS(pa, pb, slot)                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) _Pragma("unroll") for (int i = 0; i < MT; ++i) {           \
+        if (DUAL) accs[c][DUAL ? i : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], wf[slot][c][pb], accs[c][DUAL ? i : 0], 0, 0, 0); \
+        else acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][pa], wf[slot][c][pb], acc[c][i], 0, 0, 0);       \
+    }
+#define MFH(slot)                                                                                             \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) _Pragma("unroll") for (int i = 0; i < MT; ++i)             \
+        acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], wf[slot][c][0], acc[c][i], 0, 0, 0);
+#define RD(addr, pl)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
+        af[i][pl] = *reinterpret_cast<const bf16x8*>(smem + (addr) + (pl) * PLANE + i * 2048);
+#define SPLIT_ROW(i_)                                                                                         \
+    if ((i_) < MT) { a_store_row(wr, (i_)); a_load_row(kt + 3, (i_)); }
+    RD(rofs0, 2) RD(rofs0, 1) RD(rofs0, 0)
+    SB;
+    long long t_main = 0;
+    if (p.stamps) t_main = __builtin_amdgcn_s_memtime();
+    int cur = 0, nxt = BUF, wr = 2 * BUF;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int a1 = cur + rofs1, a0n = nxt + rofs0;
+        MFS(2, 0, 0) RD(a1, 2) SB;
+        MFS(1, 1, 0) SPLIT_ROW(0) SB;
+        MFS(1, 0, 0) RD(a1, 1) SB;
+        MFS(0, 2, 0) SPLIT_ROW(1) SB;
+        MFS(0, 1, 0) SPLIT_ROW(2) SB;
+        MFH(0) RD(a1, 0) w_load(2 * kt + 2, 0); SB;
+        MFS(2, 0, 1) RD(a0n, 2) SB;
+        MFS(1, 1, 1) SPLIT_ROW(3) SB;
+        MFS(1, 0, 1) RD(a0n, 1) SB;
+        MFS(0, 2, 1) SPLIT_ROW(4) SB;
+        MFS(0, 1, 1) SPLIT_ROW(5) SB;
+        MFH(1) RD(a0n, 0) w_load(2 * kt + 3, 1); SB;
+        __builtin_amdgcn_s_waitcnt(0xC07F | (MT << 8));
+        __builtin_amdgcn_s_barrier();
+        SB;
+        const int t = cur; cur = nxt; nxt = wr; wr = t;
+    }
+#undef SB
+#undef MFS
+#undef MFH
+#undef RD
+#undef SPLIT_ROW
+    long long t_epi = 0;
+    if (p.stamps) t_epi = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    split_epilogue_w4<MT, DUAL>(p, smem, acc, accs, m0, n0, wave, lane);
+    if (p.stamps && tid == 0) {
+        long long* o = p.stamps + 8 * (long)blockIdx.x;
+        o[0] = t_start; o[1] = t_main; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memtime();
+        o[4] = id; o[5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+        o[6] = r_start; o[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -310,25 +751,50 @@ int pick_mt(long M, int N) {
     return best;
 }
 
+// WD_SPLIT_KERNEL = ring (8 waves, wave tile 32 MT x 32) | k64 (double-buffered K-64 structure) | w4 (4 waves, wave tile 32 MT x 64) |
+// w4d (w4 with the second accumulator set)
+int kernel_choice() {
+    static const int v = []() {
+        const char* e = getenv("WD_SPLIT_KERNEL");
+        if (!e) return 0;
+        return !strcmp(e, "k64") ? 1 : !strcmp(e, "w4") ? 2 : !strcmp(e, "w4d") ? 3 : 0;
+    }();
+    return v;
+}
+
 template <int MT, int MODE>
 int launch(const SplitArgs& a, hipStream_t stream) {
-    constexpr size_t lds_main = 2u * 3u * 32u * MT * 128u, lds_epi = 32u * (MT < 3 ? MT : 3) * BN * 4u;
-    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    const int kc = kernel_choice();
+    constexpr size_t lds_epi = 32u * (MT < 3 ? MT : 3) * BN * 4u;
+    constexpr size_t lds_k64 = 2u * 3u * 32u * MT * 128u, lds_ring = 3u * 3u * 32u * MT * 64u;
+    const size_t lds_main = kc == 1 ? lds_k64 : lds_ring;
+    const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    const void* fn = kc == 1 ? reinterpret_cast<const void*>(gemm_split_k64_kernel<MT, MODE>)
+                   : kc == 2 ? reinterpret_cast<const void*>(gemm_split_w4_kernel<MT, MODE, false>)
+                   : kc == 3 ? reinterpret_cast<const void*>(gemm_split_w4_kernel<MT, MODE, true>)
+                             : reinterpret_cast<const void*>(gemm_split_kernel<MT, MODE>);
     static bool attr_set[16] = {};
     int dev = 0;
     WT_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<MT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        WT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     const int total = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((gemm_split_kernel<MT, MODE>), dim3((unsigned)((total + 7) / 8 * 8)), dim3(NTHREADS), lds, stream, a);
+    const dim3 grid((unsigned)((total + 7) / 8 * 8));
+    if (kc == 1) hipLaunchKernelGGL((gemm_split_k64_kernel<MT, MODE>), grid, dim3(NTHREADS), lds, stream, a);
+    else if (kc == 2) hipLaunchKernelGGL((gemm_split_w4_kernel<MT, MODE, false>), grid, dim3(W4_THREADS), lds, stream, a);
+    else if (kc == 3) hipLaunchKernelGGL((gemm_split_w4_kernel<MT, MODE, true>), grid, dim3(W4_THREADS), lds, stream, a);
+    else hipLaunchKernelGGL((gemm_split_kernel<MT, MODE>), grid, dim3(NTHREADS), lds, stream, a);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
 
+long long* g_stamps = nullptr;           // diagnostics (wd_gemm_split_debug_stamps)
+
 template <int MODE>
 int dispatch(SplitArgs& a, hipStream_t stream) {
+    a.stamps = g_stamps;
     const int mt = pick_mt(a.M, a.N);
     a.tiles_m = (a.M + 32 * mt - 1) / (32 * mt);
     a.tiles_n = (a.N + BN - 1) / BN;
@@ -345,6 +811,13 @@ int dispatch(SplitArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" {
+
+/* Diagnostics: following launches write eight int64 per workgroup (s_memtime at start / main loop / epilogue / end, tile id, XCC id,
+ * s_memrealtime at start / end) to `buf` (device memory, 8 x grid size entries; nullptr switches it off).  tools/gemm_split_stamps.py */
+int wd_gemm_split_debug_stamps(long long* buf) {
+    g_stamps = buf;
+    return WT_OK;
+}
 
 size_t wd_gemm_split_packed_bytes(int N, int K) {
     if (N <= 0 || K <= 0 || (K % BK)) return 0;
