@@ -72,10 +72,14 @@ int wd_gemm_lt_plan_info(int m, int n, int k, int relu, int has_bias, int has_re
  *                               out (batch, Ho, Wo, N) NHWC with the same fused epilogue. */
 size_t wd_gemm_split_packed_bytes(int N, int K);
 int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* stream);
+/* Shapes with few output tiles (FPN p5 / p6 convolutions, the box-head FC) are cut into K slices whose partial tiles meet in `workspace`
+ * (wd_gemm_split_workspace(M, N, K) bytes; M = batch * Ho * Wo, K = ksize^2 * C for the convolution) and are summed in slice order by a second
+ * launch: deterministic.  workspace may be NULL / smaller: the call then runs unsliced. */
+size_t wd_gemm_split_workspace(long M, int N, int K);
 int wd_gemm_split_f32(const float* a, long lda, const void* packed_w, const float* bias, const float* residual, float* out, long ldc,
-                      int M, int N, int K, int relu, void* stream);
+                      int M, int N, int K, int relu, void* workspace, size_t workspace_bytes, void* stream);
 int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void* packed_w, int ksize, int stride, int pad, const float* bias,
-                      const float* residual, float* out, int N, int relu, void* stream);
+                      const float* residual, float* out, int N, int relu, void* workspace, size_t workspace_bytes, void* stream);
 /* diagnostics: per-workgroup s_memtime stamps of the following wd_gemm_split_f32 / wd_conv_split_f32 launches (8 int64 per workgroup; NULL = off) */
 int wd_gemm_split_debug_stamps(long long* buf);
 /* wd_nms_sorted_f32 on n_seg (<= 8) independent row ranges in one pair of launches: detectron2's per-level batched_nms of the RPN

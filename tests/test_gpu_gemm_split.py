@@ -153,6 +153,31 @@ def test_split_conv_box_head_shape_error_gate(ops):
     print('box-head conv error vs f64: split %s, f32 chain %s, MIOpen %s' % (e, e32, e_lib))
 
 
+@pytest.mark.parametrize('m,n,k', [(600, 256, 2304), (2400, 256, 2048), (1000, 1024, 12544), (150, 512, 1024)])
+def test_split_gemm_k_sliced_small_shapes(ops, m, n, k):
+    """Few output tiles (FPN p5 / p6, box-head FC): the kernel cuts K into slices, a second launch sums the partial tiles in slice order -
+    same error gate, fused epilogue intact, bit-identical from run to run."""
+    import ctypes as C
+    from waymo_2d_tracking_amd import _lib
+    assert int(_lib.lib().wd_gemm_split_workspace(C.c_long(m), C.c_int(n), C.c_int(k))) > 0          # this shape IS sliced
+    torch.manual_seed(k + m)
+    a = torch.randn(m, k, device='cuda')
+    w = torch.randn(n, k, device='cuda') / k ** 0.5
+    bias = torch.randn(n, device='cuda')
+    res = torch.randn(m, n, device='cuda')
+    pw = ops.split_pack_weight(w)
+    ref = a.double() @ w.double().t()
+    y = ops.gemm_split(a, pw, n)
+    e, e32 = _err(y, ref), _err(_chain_f32(ops, a, w), ref)
+    assert e[1] <= 1.25 * e32[1] and e[0] <= 1.25 * e32[0], (e, e32)
+    y2 = ops.gemm_split(a, pw, n, bias, res, True)
+    assert float((y2.double() - (ref + bias.double() + res.double()).relu()).abs().max()) <= 2e-5
+    assert torch.equal(ops.gemm_split(a, pw, n, bias, res, True), y2)
+    buf = res.clone()
+    ops.gemm_split(a, pw, n, bias, buf, True, out=buf)                  # in place on the residual
+    assert torch.equal(buf, y2)
+
+
 def test_split_gemm_rejects_unsupported_shapes(ops):
     from waymo_2d_tracking_amd._lib import WaymoTrackError
     a = torch.randn(64, 96, device='cuda')

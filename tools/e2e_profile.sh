@@ -2,6 +2,7 @@
 # steady-state kernel breakdown of one frame of the default bench (kernel trace, last frames only)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
+export WT_BENCH_NO_EXACT=1   # the trace must end with the headline pipeline, not the exact-f32 secondary run
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_e2e -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/e2e.json 2>/tmp/e2e.log
 python3 - "$(find /tmp/prof_e2e -name '*kernel_trace.csv' | head -1)" $R/gpurun_out/e2e_frame_sequence.txt > $R/gpurun_out/e2e_steady.txt <<'PY'
 import csv, sys, collections

@@ -54,6 +54,8 @@ struct SplitArgs {
     long lda, ldc;                // row strides (floats) of a (plain mode) and of out / residual
     int M, N, K, relu;
     int tiles_m, tiles_n, xmap;
+    int splitk;                   // K slices per output tile (ring kernel); > 1: raw partial tiles go to part[slice][M][N]
+    float* part;
     long long* stamps;            // debug: per-workgroup s_memtime stamps (start, main loop, epilogue, end) or nullptr
     // convolution mode: a = NHWC (batch, H, W, C); output pixel grid (Ho, Wo); K = taps * C
     int H, W, C, Ho, Wo, stride, pad, ksize;
@@ -291,6 +293,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_k64_kernel(const Split
 // complete and visible for the whole of step j: the last slots of a step prefetch the next step's fragments ACROSS the barrier, whose
 // wait is a counted lgkmcnt (the LDS writes are older than the MT outstanding prefetch reads).  One barrier per 2 x 6 MT MFMAs, no drain.
 // A rows are staged as float2 per thread (160 rows x 32 floats / 512 threads = 5 float2), three ds_write_b32 per row block.
+#ifndef WD_ABL
+#define WD_ABL 0
+#endif
 template <int MT, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     constexpr int BUF = 3 * PLANE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int total = p.tiles_m * p.tiles_n;
+    const int total = p.tiles_m * p.tiles_n * p.splitk;
     int id;
     {
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -309,28 +314,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     }
     long long t_start = 0, r_start = 0;
     if (p.stamps) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
+    // split-K: the slices of one tile are neighbours (same XCD); slice kz covers K steps [k0, k0 + nk)
+    const int kz = id % p.splitk;
+    id /= p.splitk;
     int tm, tn;
     if (p.xmap == 0) { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; } else { tn = id / p.tiles_m; tm = id - tn * p.tiles_m; }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = p.K / 32;
+    const int nk_all = p.K / 32;
+    const int per = (nk_all + p.splitk - 1) / p.splitk;
+    const int k0 = kz * per;
+    const int nk = (k0 + per <= nk_all) ? per : nk_all - k0;
 
     // ---- A staging: thread -> (row srow + 32 i, float2 sk2 of the 32-float K step) ----
     const int srow = tid >> 4, sk2 = tid & 15;
-    int aoff[MT];
+    unsigned aoff[MT];                            // 32-bit element offsets against the scalar base pointer (MODE 1: may wrap below 0 for padded taps)
     unsigned vmask[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int m = m0 + srow + 32 * i;
         m = m < p.M ? m : p.M - 1;
         if (MODE == 0) {
-            aoff[i] = (int)(m * p.lda) + 2 * sk2;
+            aoff[i] = (unsigned)(m * p.lda) + 2u * sk2;
             vmask[i] = 1u;
         } else {
             const int hw = p.Ho * p.Wo;
             const int b = m / hw, rem = m - b * hw;
             const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
             const int y0 = yo * p.stride - p.pad, x0 = xo * p.stride - p.pad;
-            aoff[i] = ((b * p.H + y0) * p.W + x0) * p.C + 2 * sk2;
+            aoff[i] = (unsigned)(((b * p.H + y0) * p.W + x0) * p.C + 2 * sk2);
             unsigned vm = 0;
             for (int t = 0; t < p.ksize * p.ksize; ++t) {
                 const int yy = y0 + t / p.ksize, xx = x0 + t % p.ksize;
@@ -342,16 +353,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     const int kc = (MODE == 1) ? p.C / 32 : 1;    // K steps per tap
     float2 araw[MT];
     auto a_load_row = [&](int kt, int i) {          // row block i of K step kt (clamped) -> araw[i]
-        kt = kt < nk ? kt : nk - 1;
+        kt = k0 + (kt < nk ? kt : nk - 1);
+#if WD_ABL & 128
+        kt = k0;
+#endif
         if (MODE == 0) {
-            araw[i] = *reinterpret_cast<const float2*>(p.a + (aoff[i] + kt * 32));
+            araw[i] = *reinterpret_cast<const float2*>(p.a + (size_t)(aoff[i] + (unsigned)(kt * 32)));
         } else {
             const int tap = kt / kc, cb = kt - tap * kc;
             const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
-            const int delta = (dy * p.W + dx) * p.C + cb * 32;
+            const unsigned delta = (unsigned)((dy * p.W + dx) * p.C + cb * 32);
             const bool ok = ((vmask[i] >> tap) & 1u) != 0;
-            const int off = ok ? aoff[i] + delta : 2 * sk2;               // always a valid address; zeroed below
-            const float2 v = *reinterpret_cast<const float2*>(p.a + off);
+            const unsigned off = ok ? aoff[i] + delta : 2u * sk2;         // always a valid address; zeroed below
+            const float2 v = *reinterpret_cast<const float2*>(p.a + (size_t)off);
             araw[i] = ok ? v : make_float2(0.f, 0.f);
         }
     };
@@ -372,7 +386,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     const int nsub = nk * 2;
     bf16x8 wf[2][3];
     auto w_load = [&](int sub, int slot) {
-        sub = sub < nsub ? sub : nsub - 1;
+        sub = 2 * k0 + (sub < nsub ? sub : nsub - 1);
+#if WD_ABL & 64
+        sub = 2 * k0 + (sub & 1);
+#endif
         const uint4* q = wbase + (size_t)sub * 192;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) wf[slot][pl] = __builtin_bit_cast(bf16x8, q[pl * 64]);
@@ -404,10 +421,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     bf16x8 af[MT][3];
 #define SB __builtin_amdgcn_sched_barrier(0)
     // compile-time ablations for tools/split_ablation.sh (timing only, results wrong): WD_ABL bit 0 no A global loads, 1 no split / LDS
-    // writes, 2 no W loads, 3 no barrier, 4 no MFMAs, 5 no fragment reads
-#ifndef WD_ABL
-#define WD_ABL 0
-#endif
+    // writes, 2 no W loads, 3 no barrier, 4 no MFMAs, 5 no fragment reads, 6 W loads always from K step 0 (cache hits), 7 A loads always from K step 0
 #if WD_ABL & 16
 #define MF(pa, pb, slot)                                                                                      \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(af[i][pa]), "v"(wf[slot][pb]));
@@ -475,7 +489,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     if (p.stamps) t_epi = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);          // the dangling prefetch of the step behind the last one
     __builtin_amdgcn_s_barrier();
-    split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane);
+    if (p.splitk > 1) {                            // raw partial tile of this K slice; bias / residual / ReLU in the reduce launch
+        SplitArgs q = p;
+        q.out = p.part + (size_t)kz * p.M * p.N;
+        q.ldc = p.N;
+        q.bias = nullptr; q.residual = nullptr; q.relu = 0;
+        split_epilogue<MT>(q, smem, acc, m0, n0, wave, lane);
+    } else {
+        split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane);
+    }
     if (p.stamps && tid == 0) {
         long long* o = p.stamps + 8 * (long)blockIdx.x;
         o[0] = t_start; o[1] = t_main; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memtime();
@@ -735,21 +757,56 @@ __global__ __launch_bounds__(256) void gemm_split_pack_kernel(const float* __res
     dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-int pick_mt(long M, int N) {
-    // rows per tile = 32 MT: the fewest idle CU-rounds on 256 CUs wins, ties to the larger tile (fewer passes over W)
-    static const int forced = []() { const char* e = getenv("WD_SPLIT_MT"); return e ? atoi(e) : 0; }();
-    if (forced >= 2 && forced <= 5) return forced;
+// out = act(sum over the K slices in slice order + bias + residual): deterministic, one float4 per thread
+__global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float4* __restrict__ part, int splitk, long mn4, int n4, const float4* __restrict__ bias,
+                                                                const float* __restrict__ residual, long ldc, int relu, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn4) return;
+    float4 v = part[i];
+    for (int z = 1; z < splitk; ++z) {
+        const float4 q = part[(size_t)z * mn4 + i];
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    const long row = i / n4;
+    const int c4 = (int)(i - row * n4);
+    if (bias) { const float4 b = bias[c4]; v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    const size_t o = (size_t)row * ldc + 4 * c4;
+    if (residual) { const float4 q = *reinterpret_cast<const float4*>(residual + o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(out + o) = v;
+}
+
+// Tile height (32 MT rows) and K slices for a shape.  Cost model in microseconds from the measured ring kernel (MI355X, profiles/r05_split_*):
+// a K step of 32 costs ~0.52 us per 32-row block of the tile, prologue + epilogue ~(2 + MT) us per workgroup, 256 workgroups run at once;
+// a split adds the reduce launch (3 us + the partial tiles through HBM at ~4 TB/s).  Shapes with few tiles (FPN p5 / p6, the box-head FC)
+// fill the chip through K slices; large ones pick the tile height with the fewest idle CU-rounds.
+struct Plan { int mt, splitk; };
+
+Plan pick_plan(long M, int N, int K, bool allow_split) {
+    static const int forced_mt = []() { const char* e = getenv("WD_SPLIT_MT"); return e ? atoi(e) : 0; }();
+    static const int forced_sk = []() { const char* e = getenv("WD_SPLIT_SPLITK"); return e ? atoi(e) : 0; }();
     const long tn = (N + BN - 1) / BN;
-    int best = 5;
-    double best_cost = 1e30;
+    const int nk_all = K / 32;
+    Plan best{5, 1};
+    double best_t = 1e30;
     for (int mt = 5; mt >= 2; --mt) {            // MT = 6 needs more than 256 registers
+        if (forced_mt >= 2 && forced_mt <= 5 && mt != forced_mt) continue;
         const long tiles = ((M + 32 * mt - 1) / (32 * mt)) * tn;
-        const long rounds = (tiles + 255) / 256;
-        const double cost = (double)rounds * mt;                  // time ~ rounds x rows per tile
-        if (cost < best_cost * 0.999) { best_cost = cost; best = mt; }
+        for (int sk = 1; sk <= 32; ++sk) {
+            if (sk > 1 && !allow_split) break;
+            if (forced_sk >= 1 && sk != forced_sk && allow_split) continue;
+            const int per = (nk_all + sk - 1) / sk;
+            if (sk > 1 && (per < 3 || (long)(sk - 1) * per >= nk_all)) continue;
+            const long rounds = (tiles * sk + 255) / 256;
+            double t = rounds * (mt * per * 0.52 + 2.0 + mt);
+            if (sk > 1) t += 3.0 + (double)(sk + 1) * M * N * 4.0 / 4.0e6;
+            if (t < best_t * 0.97) { best_t = t; best = Plan{mt, sk}; }      // ties to the larger tile / fewer slices
+        }
     }
     return best;
 }
+
+long long* g_stamps = nullptr;           // diagnostics (wd_gemm_split_debug_stamps)
 
 // WD_SPLIT_KERNEL = ring (8 waves, wave tile 32 MT x 32) | k64 (double-buffered K-64 structure) | w4 (4 waves, wave tile 32 MT x 64) |
 // w4d (w4 with the second accumulator set)
@@ -780,7 +837,7 @@ int launch(const SplitArgs& a, hipStream_t stream) {
         WT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    const int total = a.tiles_m * a.tiles_n;
+    const int total = a.tiles_m * a.tiles_n * a.splitk;
     const dim3 grid((unsigned)((total + 7) / 8 * 8));
     if (kc == 1) hipLaunchKernelGGL((gemm_split_k64_kernel<MT, MODE>), grid, dim3(NTHREADS), lds, stream, a);
     else if (kc == 2) hipLaunchKernelGGL((gemm_split_w4_kernel<MT, MODE, false>), grid, dim3(W4_THREADS), lds, stream, a);
@@ -790,22 +847,32 @@ int launch(const SplitArgs& a, hipStream_t stream) {
     return WT_OK;
 }
 
-long long* g_stamps = nullptr;           // diagnostics (wd_gemm_split_debug_stamps)
-
 template <int MODE>
-int dispatch(SplitArgs& a, hipStream_t stream) {
+int dispatch(SplitArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     a.stamps = g_stamps;
-    const int mt = pick_mt(a.M, a.N);
+    const bool can_split = kernel_choice() == 0 && workspace != nullptr && (a.N % 4) == 0;
+    Plan pl = pick_plan(a.M, a.N, a.K, can_split);
+    if (pl.splitk > 1 && workspace_bytes < (size_t)pl.splitk * a.M * a.N * sizeof(float)) pl = pick_plan(a.M, a.N, a.K, false);
+    const int mt = pl.mt;
+    a.splitk = pl.splitk;
+    a.part = pl.splitk > 1 ? (float*)workspace : nullptr;
     a.tiles_m = (a.M + 32 * mt - 1) / (32 * mt);
     a.tiles_n = (a.N + BN - 1) / BN;
     static const int xmap = []() { const char* e = getenv("WD_SPLIT_XMAP"); return e ? atoi(e) : 0; }();
     a.xmap = xmap;
+    int rc;
     switch (mt) {
-        case 2: return launch<2, MODE>(a, stream);
-        case 3: return launch<3, MODE>(a, stream);
-        case 4: return launch<4, MODE>(a, stream);
-        default: return launch<5, MODE>(a, stream);
+        case 2: rc = launch<2, MODE>(a, stream); break;
+        case 3: rc = launch<3, MODE>(a, stream); break;
+        case 4: rc = launch<4, MODE>(a, stream); break;
+        default: rc = launch<5, MODE>(a, stream); break;
     }
+    if (rc != WT_OK || a.splitk == 1) return rc;
+    const long mn4 = (long)a.M * a.N / 4;
+    hipLaunchKernelGGL(gemm_split_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, stream, (const float4*)a.part, a.splitk, mn4, a.N / 4,
+                       (const float4*)a.bias, a.residual, a.ldc, a.relu, a.out);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
 }
 
 }  // namespace
@@ -836,8 +903,15 @@ int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* 
     return WT_OK;
 }
 
+/* Bytes of scratch the K-sliced form of a shape wants (0: the shape runs unsliced).  Passing less (or NULL) is legal: the call then runs unsliced. */
+size_t wd_gemm_split_workspace(long M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 32) || kernel_choice() != 0) return 0;
+    const Plan pl = pick_plan(M, N, K, true);
+    return pl.splitk > 1 ? (size_t)pl.splitk * M * N * sizeof(float) : 0;
+}
+
 int wd_gemm_split_f32(const float* a, long lda, const void* packed_w, const float* bias, const float* residual, float* out, long ldc,
-                      int M, int N, int K, int relu, void* stream_) {
+                      int M, int N, int K, int relu, void* workspace, size_t workspace_bytes, void* stream_) {
     WT_TRY(wt::ensure_device());
     if (M <= 0 || N <= 0) return WT_OK;
     if (!a || !packed_w || !out || K <= 0 || (K % BK) || (N % 32) || (lda & 3) || (ldc & 3) || ((uintptr_t)a & 15) || ((uintptr_t)packed_w & 15) ||
@@ -849,11 +923,11 @@ int wd_gemm_split_f32(const float* a, long lda, const void* packed_w, const floa
     SplitArgs s{};
     s.a = a; s.w = (const uint4*)packed_w; s.bias = bias; s.residual = residual; s.out = out;
     s.lda = lda; s.ldc = ldc; s.M = M; s.N = N; s.K = K; s.relu = relu;
-    return dispatch<0>(s, (hipStream_t)stream_);
+    return dispatch<0>(s, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void* packed_w, int ksize, int stride, int pad, const float* bias,
-                      const float* residual, float* out, int N, int relu, void* stream_) {
+                      const float* residual, float* out, int N, int relu, void* workspace, size_t workspace_bytes, void* stream_) {
     WT_TRY(wt::ensure_device());
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const long M = (long)batch * Ho * Wo;
@@ -868,7 +942,7 @@ int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void
     s.a = x; s.w = (const uint4*)packed_w; s.bias = bias; s.residual = residual; s.out = out;
     s.lda = C; s.ldc = N; s.M = (int)M; s.N = N; s.K = ksize * ksize * C; s.relu = relu;
     s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.stride = stride; s.pad = pad; s.ksize = ksize;
-    return dispatch<1>(s, (hipStream_t)stream_);
+    return dispatch<1>(s, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 }  // extern "C"

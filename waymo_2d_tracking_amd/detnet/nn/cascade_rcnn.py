@@ -398,6 +398,7 @@ class BoxHead(nn.Module):
         self.box_weight = nn.Parameter(torch.empty(4, 1024).normal_(0, 0.001, generator=gen), requires_grad=False)
         self.box_bias = nn.Parameter(torch.zeros(4), requires_grad=False)
         self._split = [_PackedSplit() for _ in range(4)]
+        self._split_fc = _PackedSplit()
 
     def forward(self, x):
         train = torch.is_grad_enabled()
@@ -419,6 +420,10 @@ class BoxHead(nn.Module):
         flat = x.permute(0, 2, 3, 1).reshape(r, -1)           # NHWC flatten, a view
         if train:
             h = F.relu(F.linear(flat, self.fc1_weight, self.fc1_bias))
+        elif x.is_cuda and _split_ok(self.fc1_weight.shape[1], self.fc1_weight.shape[0]):
+            # 12544 -> 1024 on the split-operand kernel, K cut into slices (32 output tiles would leave 7/8 of the chip idle)
+            h = ops.gemm_split(flat if flat.is_contiguous() else flat.contiguous(), self._split_fc.get(self.fc1_weight), self.fc1_weight.shape[0],
+                               self.fc1_bias, None, True)
         else:
             h = ops.gemm_nt(flat, self.fc1_weight, self.fc1_bias, None, True)
         logits = F.linear(h, self.cls_weight, self.cls_bias)

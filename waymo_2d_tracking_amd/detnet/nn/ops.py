@@ -341,6 +341,21 @@ def _split_log_end(e0, tag, m, n, k):
     EVENT_LOG.append((tag, 12.0 * m * n * k, e0, e1))
 
 
+_SPLIT_WS_BYTES = {}
+
+
+def _split_workspace(m, n, k, device):
+    """Scratch for the K-sliced form of a small shape (wd_gemm_split_workspace; None for shapes that run unsliced).  A fresh tensor per call from
+    torch's caching allocator: stream-ordered reuse, safe under hipGraph capture."""
+    key = (m, n, k)
+    nbytes = _SPLIT_WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _SPLIT_WS_BYTES[key] = int(_lib.lib().wd_gemm_split_workspace(C.c_long(m), C.c_int(n), C.c_int(k)))
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 def split_pack_weight(weight):
     """(N, K) f32 GEMM weight, or an (N, C, 3, 3) / (N, C, 1, 1) convolution weight -> packed bf16 planes (hi, mid, lo) in MFMA fragment order
     for gemm_split / conv_split (wd_gemm_split_pack_weight).  Convolution weights are laid out k = (kh * 3 + kw) * C + c."""
@@ -366,9 +381,10 @@ def gemm_split(a, packed, n, bias=None, residual=None, relu=False, out=None):
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     assert out.is_contiguous() and (residual is None or residual.is_contiguous())
+    ws, ws_bytes = _split_workspace(m, n, k, a.device)
     ev = _split_log_begin()
     _lib.check(_lib.lib().wd_gemm_split_f32(_p(a), C.c_long(a.stride(0)), _p(packed), _p(bias), _p(residual), _p(out), C.c_long(n), C.c_int(m),
-                                            C.c_int(n), C.c_int(k), C.c_int(1 if relu else 0), _stream()), 'wd_gemm_split_f32')
+                                            C.c_int(n), C.c_int(k), C.c_int(1 if relu else 0), _p(ws), C.c_size_t(ws_bytes), _stream()), 'wd_gemm_split_f32')
     _split_log_end(ev, 'gemm_split_kernel: 1x1 conv / GEMM M=%d N=%d K=%d' % (m, n, k), m, n, k)
     return out
 
@@ -382,9 +398,11 @@ def conv_split(x, packed, n_out, ksize, stride=1, pad=0, bias=None, residual=Non
     out = torch.empty((b, n_out, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if residual is not None:
         residual = _nhwc(residual)
+    ws, ws_bytes = _split_workspace(b * ho * wo, n_out, ksize * ksize * c, x.device)
     ev = _split_log_begin()
     _lib.check(_lib.lib().wd_conv_split_f32(_p(x), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(c), _p(packed), C.c_int(ksize), C.c_int(stride),
-                                            C.c_int(pad), _p(bias), _p(residual), _p(out), C.c_int(n_out), C.c_int(1 if relu else 0), _stream()),
+                                            C.c_int(pad), _p(bias), _p(residual), _p(out), C.c_int(n_out), C.c_int(1 if relu else 0), _p(ws), C.c_size_t(ws_bytes),
+                                            _stream()),
                'wd_conv_split_f32')
     _split_log_end(ev, 'gemm_split_kernel: %dx%d conv s%d M=%d N=%d K=%d' % (ksize, ksize, stride, b * ho * wo, n_out, ksize * ksize * c), b * ho * wo, n_out,
                    ksize * ksize * c)
