@@ -87,9 +87,22 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
     const int c4 = 4 * lane;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && c4 < ncols) bv = *reinterpret_cast<const float4*>(p.bias + n0 + c4);
+    constexpr int PASS = 3;                                     // row blocks per pass
+    constexpr int RPW = 32 * PASS / 8;                          // rows per wave and pass
 #pragma unroll
-    for (int i0 = 0; i0 < MT; i0 += 3) {
-        constexpr int PASS = 3;
+    for (int i0 = 0; i0 < MT; i0 += PASS) {
+        const int nrows = 32 * ((MT - i0) < PASS ? (MT - i0) : PASS);
+        // the residual rows of this pass are requested FIRST, all at once: they are the only reads of the epilogue that come from beyond L2
+        // (~2 us away), and twelve 1-KiB row loads per wave in flight are what it takes to pull them at more than ~10 B/clk per CU
+        float4 rv[RPW];
+        if (p.residual) {
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int r = wave + 8 * j, row = m0 + 32 * i0 + r;
+                rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < nrows && row < p.M && c4 < ncols) rv[j] = *reinterpret_cast<const float4*>(p.residual + (size_t)row * p.ldc + n0 + c4);
+            }
+        }
         if (i0 > 0) __builtin_amdgcn_s_barrier();              // the previous pass has been read
 #pragma unroll
         for (int i = i0; i < i0 + PASS && i < MT; ++i)
@@ -98,20 +111,15 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
                 ct[((i - i0) * 32 + (e & 3) + 8 * (e >> 2) + 4 * rg) * BN + 32 * wave + rr] = acc[i][e];
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
-        const int nrows = 32 * ((MT - i0) < PASS ? (MT - i0) : PASS);
-#pragma unroll 4
-        for (int r = wave; r < nrows; r += 8) {
-            const int row = m0 + 32 * i0 + r;
-            if (row < p.M && c4 < ncols) {
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int r = wave + 8 * j, row = m0 + 32 * i0 + r;
+            if (r < nrows && row < p.M && c4 < ncols) {
                 float4 v = *reinterpret_cast<const float4*>(ct + r * BN + c4);
-                const size_t o = (size_t)row * p.ldc + n0 + c4;
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (p.residual) {
-                    const float4 q = *reinterpret_cast<const float4*>(p.residual + o);
-                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-                }
+                if (p.residual) { v.x += rv[j].x; v.y += rv[j].y; v.z += rv[j].z; v.w += rv[j].w; }
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(p.out + o) = v;
+                *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + n0 + c4) = v;
             }
         }
     }
@@ -352,13 +360,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     }
     const int kc = (MODE == 1) ? p.C / 32 : 1;    // K steps per tap
     float2 araw[MT];
-    auto a_load_row = [&](int kt, int i) {          // row block i of K step kt (clamped) -> araw[i]
+    auto a_fetch = [&](int kt, int i) -> float2 {   // row block i of K step kt (clamped)
         kt = k0 + (kt < nk ? kt : nk - 1);
 #if WD_ABL & 128
         kt = k0;
 #endif
         if (MODE == 0) {
-            araw[i] = *reinterpret_cast<const float2*>(p.a + (size_t)(aoff[i] + (unsigned)(kt * 32)));
+            return *reinterpret_cast<const float2*>(p.a + (size_t)(aoff[i] + (unsigned)(kt * 32)));
         } else {
             const int tap = kt / kc, cb = kt - tap * kc;
             const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
@@ -366,18 +374,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
             const bool ok = ((vmask[i] >> tap) & 1u) != 0;
             const unsigned off = ok ? aoff[i] + delta : 2u * sk2;         // always a valid address; zeroed below
             const float2 v = *reinterpret_cast<const float2*>(p.a + (size_t)off);
-            araw[i] = ok ? v : make_float2(0.f, 0.f);
+            return ok ? v : make_float2(0.f, 0.f);
         }
     };
+    auto a_load_row = [&](int kt, int i) { araw[i] = a_fetch(kt, i); };
     const int wofs = srow * 64 + ((((sk2 >> 2) ^ ((srow >> 2) & 3))) << 4) + ((sk2 & 3) << 2);
-    auto a_store_row = [&](int bufoff, int i) {     // split row block i of araw and write its three planes (one bf16 pair each)
+    auto a_store_val = [&](int bufoff, int i, float2 v) {     // split a row block's float2 and write its three planes (one bf16 pair each)
         unsigned char* base = smem + bufoff + wofs + i * 2048;
         unsigned h, m, l;
-        split_pair(araw[i].x, araw[i].y, h, m, l);
+        split_pair(v.x, v.y, h, m, l);
         *reinterpret_cast<unsigned*>(base) = h;
         *reinterpret_cast<unsigned*>(base + PLANE) = m;
         *reinterpret_cast<unsigned*>(base + 2 * PLANE) = l;
     };
+    auto a_store_row = [&](int bufoff, int i) { a_store_val(bufoff, i, araw[i]); };
 
     // ---- W fragments: this wave's 32 columns, [K / 16][3 planes][64 lanes] uint4; one K step (two sub-steps) in registers ----
     const int nt32 = (n0 >> 5) + wave;
@@ -406,15 +416,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     const int rofs0 = rr * 64 + ((((0 + rg) ^ ((rr >> 2) & 3))) << 4);
     const int rofs1 = rr * 64 + ((((2 + rg) ^ ((rr >> 2) & 3))) << 4);
 
-    // ---- prologue: K steps 0 and 1 into buffers 0 and 1, step 2 in registers ----
+    // ---- prologue: K steps 0, 1, 2 requested at once (one HBM round trip, not three); 0 and 1 go to buffers 0 and 1, 2 stays in registers ----
+    {
+        float2 p0[MT], p1[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_load_row(0, i);
-    w_load(0, 0);
-    w_load(1, 1);
+        for (int i = 0; i < MT; ++i) p0[i] = a_fetch(0, i);
+        w_load(0, 0);
+        w_load(1, 1);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { a_store_row(0, i); a_load_row(1, i); }
+        for (int i = 0; i < MT; ++i) p1[i] = a_fetch(1, i);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { a_store_row(BUF, i); a_load_row(2, i); }
+        for (int i = 0; i < MT; ++i) a_load_row(2, i);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a_store_val(0, i, p0[i]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a_store_val(BUF, i, p1[i]);
+    }
+    long long t_main = 0;
+    if (p.stamps) t_main = __builtin_amdgcn_s_memtime();      // (an SMEM op: kept in front of the lgkmcnt(0) below, see the loop's counted waits)
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
 
@@ -453,8 +472,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #endif
     RD(rofs0, 2) RD(rofs0, 1) RD(rofs0, 0)
     SB;
-    long long t_main = 0;
-    if (p.stamps) t_main = __builtin_amdgcn_s_memtime();
     int cur = 0, nxt = BUF, wr = 2 * BUF;
     for (int kt = 0; kt < nk; ++kt) {
         const int a1 = cur + rofs1, a0n = nxt + rofs0;
@@ -781,6 +798,7 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float4* __
 // a split adds the reduce launch (3 us + the partial tiles through HBM at ~4 TB/s).  Shapes with few tiles (FPN p5 / p6, the box-head FC)
 // fill the chip through K slices; large ones pick the tile height with the fewest idle CU-rounds.
 struct Plan { int mt, splitk; };
+int kernel_choice();
 
 Plan pick_plan(long M, int N, int K, bool allow_split) {
     static const int forced_mt = []() { const char* e = getenv("WD_SPLIT_MT"); return e ? atoi(e) : 0; }();
@@ -789,8 +807,11 @@ Plan pick_plan(long M, int N, int K, bool allow_split) {
     const int nk_all = K / 32;
     Plan best{5, 1};
     double best_t = 1e30;
-    for (int mt = 5; mt >= 2; --mt) {            // MT = 6 needs more than 256 registers
-        if (forced_mt >= 2 && forced_mt <= 5 && mt != forced_mt) continue;
+    // MT = 6 fits the ring kernel's 256 registers but measured slower per row block (box-head conv: one round of 256 tiles 297 us against 274 us for
+    // 1.2 rounds of MT = 5): offered only when forced
+    const int mt_max = (kernel_choice() == 0 && forced_mt == 6) ? 6 : 5;
+    for (int mt = mt_max; mt >= 2; --mt) {
+        if (forced_mt >= 2 && forced_mt <= mt_max && mt != forced_mt) continue;
         const long tiles = ((M + 32 * mt - 1) / (32 * mt)) * tn;
         for (int sk = 1; sk <= 32; ++sk) {
             if (sk > 1 && !allow_split) break;
@@ -821,15 +842,17 @@ int kernel_choice() {
 
 template <int MT, int MODE>
 int launch(const SplitArgs& a, hipStream_t stream) {
-    const int kc = kernel_choice();
+    const int kc = MT <= 5 ? kernel_choice() : 0;           // the A/B structures exist for up to 5 row blocks
     constexpr size_t lds_epi = 32u * (MT < 3 ? MT : 3) * BN * 4u;
     constexpr size_t lds_k64 = 2u * 3u * 32u * MT * 128u, lds_ring = 3u * 3u * 32u * MT * 64u;
     const size_t lds_main = kc == 1 ? lds_k64 : lds_ring;
     const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-    const void* fn = kc == 1 ? reinterpret_cast<const void*>(gemm_split_k64_kernel<MT, MODE>)
-                   : kc == 2 ? reinterpret_cast<const void*>(gemm_split_w4_kernel<MT, MODE, false>)
-                   : kc == 3 ? reinterpret_cast<const void*>(gemm_split_w4_kernel<MT, MODE, true>)
-                             : reinterpret_cast<const void*>(gemm_split_kernel<MT, MODE>);
+    const void* fn = reinterpret_cast<const void*>(gemm_split_kernel<MT, MODE>);
+    if constexpr (MT <= 5) {
+        if (kc == 1) fn = reinterpret_cast<const void*>(gemm_split_k64_kernel<MT, MODE>);
+        if (kc == 2) fn = reinterpret_cast<const void*>(gemm_split_w4_kernel<MT, MODE, false>);
+        if (kc == 3) fn = reinterpret_cast<const void*>(gemm_split_w4_kernel<MT, MODE, true>);
+    }
     static bool attr_set[16] = {};
     int dev = 0;
     WT_HIP(hipGetDevice(&dev));
@@ -839,10 +862,12 @@ int launch(const SplitArgs& a, hipStream_t stream) {
     }
     const int total = a.tiles_m * a.tiles_n * a.splitk;
     const dim3 grid((unsigned)((total + 7) / 8 * 8));
-    if (kc == 1) hipLaunchKernelGGL((gemm_split_k64_kernel<MT, MODE>), grid, dim3(NTHREADS), lds, stream, a);
-    else if (kc == 2) hipLaunchKernelGGL((gemm_split_w4_kernel<MT, MODE, false>), grid, dim3(W4_THREADS), lds, stream, a);
-    else if (kc == 3) hipLaunchKernelGGL((gemm_split_w4_kernel<MT, MODE, true>), grid, dim3(W4_THREADS), lds, stream, a);
-    else hipLaunchKernelGGL((gemm_split_kernel<MT, MODE>), grid, dim3(NTHREADS), lds, stream, a);
+    if constexpr (MT <= 5) {
+        if (kc == 1) hipLaunchKernelGGL((gemm_split_k64_kernel<MT, MODE>), grid, dim3(NTHREADS), lds, stream, a);
+        else if (kc == 2) hipLaunchKernelGGL((gemm_split_w4_kernel<MT, MODE, false>), grid, dim3(W4_THREADS), lds, stream, a);
+        else if (kc == 3) hipLaunchKernelGGL((gemm_split_w4_kernel<MT, MODE, true>), grid, dim3(W4_THREADS), lds, stream, a);
+    }
+    if (kc == 0) hipLaunchKernelGGL((gemm_split_kernel<MT, MODE>), grid, dim3(NTHREADS), lds, stream, a);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
@@ -865,6 +890,7 @@ int dispatch(SplitArgs& a, void* workspace, size_t workspace_bytes, hipStream_t 
         case 2: rc = launch<2, MODE>(a, stream); break;
         case 3: rc = launch<3, MODE>(a, stream); break;
         case 4: rc = launch<4, MODE>(a, stream); break;
+        case 6: rc = launch<6, MODE>(a, stream); break;
         default: rc = launch<5, MODE>(a, stream); break;
     }
     if (rc != WT_OK || a.splitk == 1) return rc;
