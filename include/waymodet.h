@@ -72,6 +72,8 @@ int wd_gemm_lt_plan_info(int m, int n, int k, int relu, int has_bias, int has_re
  *                               out (batch, Ho, Wo, N) NHWC with the same fused epilogue. */
 size_t wd_gemm_split_packed_bytes(int N, int K);
 int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* stream);
+/* the same for any 2-D view: element (n, k) = w[n * stride_n + k * stride_k] (the transpose of a weight for the backward-data GEMM of training) */
+int wd_gemm_split_pack_weight_strided(const float* w, int N, int K, long stride_n, long stride_k, void* packed, void* stream);
 /* Shapes with few output tiles (FPN p5 / p6 convolutions, the box-head FC) are cut into K slices whose partial tiles meet in `workspace`
  * (wd_gemm_split_workspace(M, N, K) bytes; M = batch * Ho * Wo, K = ksize^2 * C for the convolution) and are summed in slice order by a second
  * launch: deterministic.  workspace may be NULL / smaller: the call then runs unsliced. */

@@ -178,6 +178,39 @@ def test_split_gemm_k_sliced_small_shapes(ops, m, n, k):
     assert torch.equal(buf, y2)
 
 
+def test_training_functions_forward_and_gradients_vs_float64(ops):
+    """The autograd functions of the training graph on the split-operand kernel (LinearActFn: forward + dA; ConvSplitFn: forward + dX) against
+    float64 autograd of the plain formulas; weight / bias gradients (library) ride along."""
+    torch.manual_seed(21)
+    m, n, k = 300, 512, 256
+    a = torch.randn(m, k, device='cuda', requires_grad=True)
+    w = (torch.randn(n, k, device='cuda') / k ** 0.5).requires_grad_()
+    b = torch.randn(n, device='cuda', requires_grad=True)
+    r = torch.randn(m, n, device='cuda', requires_grad=True)
+    gy = torch.randn(m, n, device='cuda')
+    y = ops.LinearActFn.apply(a, w, b, r, True)
+    (y * gy).sum().backward()
+    a64, w64, b64, r64 = (t.detach().double().requires_grad_() for t in (a, w, b, r))
+    y64 = torch.relu(a64 @ w64.t() + b64 + r64)
+    (y64 * gy.double()).sum().backward()
+    assert float((y.double() - y64).abs().max()) <= 1e-5
+    for got, ref in ((a.grad, a64.grad), (w.grad, w64.grad), (b.grad, b64.grad), (r.grad, r64.grad)):
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), float((got.double() - ref).abs().max())
+    # dense 3x3 convolution (box-head / FPN shape family), bias + ReLU fused
+    x = torch.randn(3, 256, 9, 11, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_()
+    wt = (torch.randn(256, 256, 3, 3, device='cuda') / 48.0).requires_grad_()
+    bc = torch.randn(256, device='cuda', requires_grad=True)
+    gy = torch.randn(3, 256, 9, 11, device='cuda')
+    y = ops.ConvSplitFn.apply(x, wt, bc, 1, 1, True)
+    (y * gy).sum().backward()
+    x64, w64, b64 = (t.detach().double().requires_grad_() for t in (x, wt, bc))
+    y64 = torch.relu(F.conv2d(x64, w64, b64, 1, 1))
+    (y64 * gy.double()).sum().backward()
+    assert float((y.double() - y64).abs().max()) <= 1e-5
+    for got, ref in ((x.grad, x64.grad), (wt.grad, w64.grad), (bc.grad, b64.grad)):
+        assert float((got.double() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max())), float((got.double() - ref).abs().max())
+
+
 def test_split_gemm_rejects_unsupported_shapes(ops):
     from waymo_2d_tracking_amd._lib import WaymoTrackError
     a = torch.randn(64, 96, device='cuda')

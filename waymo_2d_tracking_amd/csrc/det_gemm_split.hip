@@ -475,7 +475,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     int cur = 0, nxt = BUF, wr = 2 * BUF;
     for (int kt = 0; kt < nk; ++kt) {
         const int a1 = cur + rofs1, a0n = nxt + rofs0;
-        // sub-step 0 (fragments in registers); its slots request sub-step 1's fragments of the same buffer
+        // sub-step 0 (fragments in registers); its slots request sub-step 1's fragments of the same buffer.  The W fragments of a sub-step are
+        // reloaded right behind its last MFMA, a whole K step ahead of their next use (measured: spreading the eight waves' reloads over
+        // different slots of the other sub-step - no burst in the vector-memory path, but 2-5 slots of lead - costs 9 % of the main loop)
         MF(2, 0, 0) RD(a1, 2) SB;
         MF(1, 1, 0) SPLIT_ROW(0) SB;
         MF(1, 0, 0) RD(a1, 1) SB;
@@ -756,14 +758,15 @@ __global__ __launch_bounds__(W4_THREADS, 1) void gemm_split_w4_kernel(const Spli
 }
 
 // W (N, K) f32 -> packed planes [N32 / 32][K / 16][3][64] x 16 bytes; one thread per (column, 8 consecutive k)
-__global__ __launch_bounds__(256) void gemm_split_pack_kernel(const float* __restrict__ w, int N, int K, uint4* __restrict__ out, long total) {
+// element (n, k) of the matrix = w[n * sn + k * sk]: (K, 1) for a row-major (N, K) weight, (1, N) for the transpose of a row-major (K, N) one
+__global__ __launch_bounds__(256) void gemm_split_pack_kernel(const float* __restrict__ w, int N, int K, long sn, long sk, uint4* __restrict__ out, long total) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int k8 = K / 8;
     const int n = (int)(t / k8), kq = (int)(t - (long)n * k8);          // k = 8 kq .. 8 kq + 7
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = n < N ? w[(size_t)n * K + 8 * kq + e] : 0.f;
+    for (int e = 0; e < 8; ++e) v[e] = n < N ? w[(size_t)n * sn + (size_t)(8 * kq + e) * sk] : 0.f;
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], h[e], m[e], l[e]);
@@ -917,16 +920,21 @@ size_t wd_gemm_split_packed_bytes(int N, int K) {
     return (size_t)((N + 31) / 32) * 32 * (size_t)K * 6;
 }
 
-int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* stream_) {
+int wd_gemm_split_pack_weight_strided(const float* w, int N, int K, long stride_n, long stride_k, void* packed, void* stream_) {
     WT_TRY(wt::ensure_device());
     if (!w || !packed || N <= 0 || K <= 0 || (K % BK)) {
         wt::set_error("wd_gemm_split_pack_weight: K must be a positive multiple of %d (N=%d K=%d)", BK, N, K);
         return WT_ERR_INVALID;
     }
     const long total = (long)((N + 31) / 32) * 32 * (K / 8);
-    hipLaunchKernelGGL(gemm_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w, N, K, (uint4*)packed, total);
+    hipLaunchKernelGGL(gemm_split_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, w, N, K, stride_n, stride_k,
+                       (uint4*)packed, total);
     WT_HIP(hipGetLastError());
     return WT_OK;
+}
+
+int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* stream_) {
+    return wd_gemm_split_pack_weight_strided(w, N, K, (long)K, 1, packed, stream_);
 }
 
 /* Bytes of scratch the K-sliced form of a shape wants (0: the shape runs unsliced).  Passing less (or NULL) is legal: the call then runs unsliced. */

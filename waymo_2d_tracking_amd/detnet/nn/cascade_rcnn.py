@@ -167,6 +167,9 @@ class ConvBN(nn.Module):
                 return y
             y = y + self.bias.view(1, -1, 1, 1)
             return F.relu_(y) if relu else y
+        if (torch.is_grad_enabled() and ops.SPLIT_TRAIN and x.is_cuda and self.groups == 1 and self.weight.shape[2] in (1, 3)
+                and _split_ok(self.weight.shape[1], self.weight.shape[0])):
+            return ops.ConvSplitFn.apply(x, self.weight, self.bias, self.stride, self.pad, relu)     # training: split-operand forward and backward-data
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.pad, 1, self.groups)
         return F.relu_(y) if relu else y
 
@@ -405,6 +408,8 @@ class BoxHead(nn.Module):
         for li, (conv, norm) in enumerate(zip(self.convs, self.norms)):
             if not train and x.is_cuda and _split_ok(256, 256):
                 x = ops.conv_split(x, self._split[li].get(conv.weight), 256, 3, 1, 1)
+            elif train and ops.SPLIT_TRAIN and x.is_cuda and _split_ok(256, 256) and x.shape[0] > 0:
+                x = ops.ConvSplitFn.apply(x, conv.weight, None, 1, 1, False)
             else:
                 x = conv(x)
             if train:

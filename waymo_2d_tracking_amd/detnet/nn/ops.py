@@ -356,20 +356,25 @@ def _split_workspace(m, n, k, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
-def split_pack_weight(weight):
+def split_pack_weight(weight, transpose=False):
     """(N, K) f32 GEMM weight, or an (N, C, 3, 3) / (N, C, 1, 1) convolution weight -> packed bf16 planes (hi, mid, lo) in MFMA fragment order
-    for gemm_split / conv_split (wd_gemm_split_pack_weight).  Convolution weights are laid out k = (kh * 3 + kw) * C + c."""
-    w = weight.detach().float()
+    for gemm_split / conv_split (wd_gemm_split_pack_weight).  Convolution weights are laid out k = (kh * 3 + kw) * C + c.  transpose=True (2-D
+    weights): pack weight.T without materialising it (the backward-data GEMM of training: dA = g @ W is the NT product of g with W.T)."""
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
     if w.dim() == 4:
-        w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
-    w = w.contiguous()
+        w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    if transpose:
+        w = w.t()
     n, k = w.shape
     lib = _lib.lib()
     nbytes = int(lib.wd_gemm_split_packed_bytes(C.c_int(n), C.c_int(k)))
     if nbytes == 0:
         raise ValueError('split_pack_weight: K must be a multiple of 64 (N=%d K=%d)' % (n, k))
     packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _lib.check(lib.wd_gemm_split_pack_weight(_p(w), C.c_int(n), C.c_int(k), _p(packed), _stream()), 'wd_gemm_split_pack_weight')
+    _lib.check(lib.wd_gemm_split_pack_weight_strided(_p(w), C.c_int(n), C.c_int(k), C.c_long(w.stride(0)), C.c_long(w.stride(1)), _p(packed), _stream()),
+               'wd_gemm_split_pack_weight_strided')
     return packed
 
 
@@ -753,6 +758,51 @@ class DeformConvFn(torch.autograd.Function):
         return dx, doff, dw, None, None, None, None, None, None
 
 
+SPLIT_TRAIN = os.environ.get('WD_SPLIT_TRAIN', '1') != '0'     # A/B switch: 0 keeps the training graph's GEMMs / dense convolutions on the f32 library path
+
+
+class ConvSplitFn(torch.autograd.Function):
+    """y = act(conv2d(x, weight, bias)) for dense 3x3 / 1x1 convolutions of the training graph (FPN output convs, RPN conv, box-head convs) on the
+    split-operand kernel: forward = conv_split; backward-data (stride 1) = the same kernel on the gradient with the taps flipped and the channel
+    roles swapped; the weight gradient stays on the library (aten convolution_backward, MIOpen wrw): it contracts over the pixel axis, which the
+    kernel's K-contiguous operand layout does not offer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu):
+        x = _nhwc(x)
+        n, c, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+        y = conv_split(x, split_pack_weight(weight), n, ks, stride, pad, bias, None, relu)
+        ctx.cfg = (stride, pad, bool(relu), bias is not None)
+        ctx.save_for_backward(x, weight, y if relu else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        dy = _nhwc(dy)
+        n, c, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+        if relu:
+            b, _, ho, wo = dy.shape
+            g = act_bwd(dy.permute(0, 2, 3, 1).reshape(b * ho * wo, n), y.permute(0, 2, 3, 1).reshape(b * ho * wo, n), None, True)
+            g = g.view(b, ho, wo, n).permute(0, 3, 1, 2)
+        else:
+            g = dy
+        dx = dw = db = None
+        want_dx = ctx.needs_input_grad[0]
+        if want_dx and stride == 1 and n % 64 == 0 and c % 32 == 0:
+            # dX[ci](p) = sum over taps, co of g[co](p + pad - tap) W[co, ci, tap]: a convolution of g with the taps flipped, roles of ci / co swapped
+            wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3)                    # (C_in, C_out, kh, kw)
+            dx = conv_split(g, split_pack_weight(wt), c, ks, 1, ks - 1 - pad)
+            want_dx = False
+        if want_dx or ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gi, dw, db = torch.ops.aten.convolution_backward(g, x, weight, [n] if has_bias else None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                             [want_dx, ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]])
+            if want_dx:
+                dx = gi
+        return dx, dw, db, None, None, None
+
+
 class LinearActFn(torch.autograd.Function):
     """y = act(a @ W.T + bias [+ residual]) for the training graph (round 4): the forward is the inference path's ONE fused library call
     (bias + ReLU on the GEMM epilogue, the residual on its beta term) instead of linear + add + relu, the backward masks the incoming
@@ -760,8 +810,19 @@ class LinearActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, weight, bias, residual, relu):
-        if residual is None:
-            y = torch._addmm_activation(bias, a, weight.t(), use_gelu=False) if relu else torch.addmm(bias, a, weight.t())
+        n, k = weight.shape
+        if SPLIT_TRAIN and a.is_cuda and k % 64 == 0 and n % 32 == 0 and a.stride(1) == 1:
+            # round 5: the split-operand kernel (exact 3 x bf16 operand planes on the bf16 matrix cores), as at inference; a new output buffer -
+            # the residual belongs to autograd
+            r = None if residual is None else (residual if residual.is_contiguous() else residual.contiguous())
+            y = gemm_split(a, split_pack_weight(weight), n, bias, r, relu)
+        elif residual is None:
+            if relu and hasattr(torch, '_addmm_activation'):
+                y = torch._addmm_activation(bias, a, weight.t(), use_gelu=False)
+            else:
+                y = torch.addmm(bias, a, weight.t())
+                if relu:
+                    y = y.relu_()
         else:
             r = residual if residual.is_contiguous() else residual.contiguous()
             y = gemm_lt(a if a.is_contiguous() else a.contiguous(), weight, bias, r, relu)
@@ -775,7 +836,13 @@ class LinearActFn(torch.autograd.Function):
         a, weight, y = ctx.saved_tensors
         dy = dy if dy.is_contiguous() else dy.contiguous()
         g = act_bwd(dy, y, None, True) if ctx.relu else dy
-        da = g @ weight if ctx.needs_input_grad[0] else None
+        n, k = weight.shape
+        if not ctx.needs_input_grad[0]:
+            da = None
+        elif SPLIT_TRAIN and g.is_cuda and n % 64 == 0 and k % 32 == 0:
+            da = gemm_split(g, split_pack_weight(weight, transpose=True), k)          # dA (M, K) = g (M, N) . (W^T)^T: W^T packed as a (K, N) weight
+        else:
+            da = g @ weight
         dw = g.t() @ a if ctx.needs_input_grad[1] else None
         db = g.sum(0) if ctx.needs_input_grad[2] else None
         dr = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
