@@ -18,7 +18,8 @@ for v in "$@"; do
   if [ -n "$lib" ]; then export WT_LIB_PATH=$R/waymo_2d_tracking_amd/csrc/variants/$lib; else unset WT_LIB_PATH; fi
   echo "== $name" >> $OUT
   i=0
-  for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"; do
+  for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" \
+             "TCP_PENDING_STALL_CYCLES_sum TA_BUSY_sum TCP_TA_DATA_STALL_CYCLES_sum TA_TA_BUSY_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_WAVES"; do
     i=$((i+1))
     rm -rf /tmp/roipmc
     timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/roipmc -- python3 /tmp/roi_only.py > /tmp/roipmc.log 2>&1
