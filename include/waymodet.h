@@ -84,6 +84,9 @@ int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void
                       const float* residual, float* out, int N, int relu, void* workspace, size_t workspace_bytes, void* stream);
 /* diagnostics: per-workgroup s_memtime stamps of the following wd_gemm_split_f32 / wd_conv_split_f32 launches (8 int64 per workgroup; NULL = off) */
 int wd_gemm_split_debug_stamps(long long* buf);
+/* diagnostics: canary workgroups (LDS / register / VALU / MFMA self-checks) for co-residency experiments; flags: 5 device uint32 counters */
+int wd_debug_canary(int workgroups, int lds_bytes, int spins, unsigned* flags, void* stream);
+int wd_debug_occupy(int workgroups, int lds_bytes, long long ticks, unsigned* sink, void* stream);
 /* wd_nms_sorted_f32 on n_seg (<= 8) independent row ranges in one pair of launches: detectron2's per-level batched_nms of the RPN
  * (find_top_rpn_proposals) with the levels' suppression chains in parallel workgroups.  Every range is sorted by descending
  * score; idxs may still mark rows that must not suppress (group -1).  n_keep: n_seg device ints. */

@@ -1,0 +1,77 @@
+"""Concurrency bisect at module level: stem + the first NB bottleneck blocks of res2.. on two streams vs serial (new image per iteration)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
+from waymo_2d_tracking_amd.detnet.nn import ops
+torch.backends.cudnn.deterministic = True
+NIT = int(os.environ.get('DIAG_ITERS', '10'))
+NB = int(os.environ.get('DIAG_BLOCKS', '50'))
+ms = [Detectron2Det(seed=5).cuda().eval(), Detectron2Det(seed=6).cuda().eval()]
+g = torch.Generator().manual_seed(0)
+imgs = [[torch.randint(0, 256, (1, 256, 384, 3), generator=g, dtype=torch.uint8).cuda() for _ in range(2)] for _ in range(NIT)]
+
+
+PRE = {}
+
+
+def run(m, img):
+    with torch.no_grad():
+        bb = m.model.backbone
+        key = (id(m), img.data_ptr())
+        if os.environ.get('DIAG_PRESTEM') == '1' and key in PRE:
+            x = PRE[key].clone()                       # stem + max-pool taken from the serial pass: no MIOpen / pooling launch in the concurrent one
+        else:
+            xn, _ = ops.preprocess(img, 1.0, False, False, True, (103.530, 116.280, 123.675), (57.375, 57.120, 58.395), 32)
+            x = bb.stem(xn, relu=True)
+            x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+            PRE[key] = x.clone()
+        outs = [x.clone()]
+        if os.environ.get('DIAG_FIRST') == '1':            # only the first two 1x1 convs behind the max-pool
+            b0 = bb.res2[0]
+            outs.append(b0.shortcut(x).clone())
+            outs.append(b0.conv1(x, relu=True).clone())
+            return outs
+        n = 0
+        for stage in (bb.res2, bb.res3, bb.res4, bb.res5):
+            for blk in stage:
+                if n >= NB:
+                    break
+                if n == 47 and os.environ.get('DIAG_DETAIL') == '1':      # res5 block 0 step by step
+                    from waymo_2d_tracking_amd.detnet.nn import cascade_rcnn as cr
+                    outs.append(x.clone())                                     # 48: its input once more
+                    sc = blk.shortcut(x, stride=2); outs.append(sc.clone())    # 49
+                    o1 = blk.conv1(x, relu=True); outs.append(o1.clone())      # 50
+                    off = blk.conv2_offset(o1); outs.append(off.clone())       # 51
+                    o2 = ops.deform_conv3x3(o1, off, blk.packed_weight(), cr.GROUPS, 2, 1, blk.conv2_scale, blk.conv2_bias, relu=True)
+                    outs.append(o2.clone())                                    # 52
+                    x = blk.conv3(o2, relu=True, residual=sc); outs.append(x.clone())   # 53
+                    n += 1
+                    continue
+                x = blk(x)
+                n += 1
+                outs.append(x.clone())
+    return outs
+
+
+run(ms[0], imgs[0][0]); run(ms[1], imgs[0][1])
+refs = []
+for it in range(NIT):
+    refs.append([run(ms[i], imgs[it][i]) for i in range(2)])
+    torch.cuda.synchronize()
+s = [torch.cuda.Stream(), torch.cuda.Stream()]
+first = {}
+for it in range(NIT):
+    got = [None, None]
+    for i in range(2):
+        with torch.cuda.stream(s[i]):
+            got[i] = run(ms[i], imgs[it][i])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for b, (x, y) in enumerate(zip(refs[it][i], got[i])):
+            if not torch.equal(x, y):
+                first[(it, i)] = (b, float((x - y).abs().max()))
+                break
+print('first differing block per (iteration, stream):', first)

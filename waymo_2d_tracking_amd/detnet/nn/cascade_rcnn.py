@@ -44,8 +44,13 @@ FUSED_TRAINING_EPILOGUES = True
 SPLIT_GEMM = os.environ.get('WD_SPLIT_GEMM', '1') != '0'
 
 
-def _split_ok(cin, cout):
-    return SPLIT_GEMM and cin % 64 == 0 and cout % 32 == 0
+_SKIP = set(os.environ.get('WD_SPLIT_SKIP', '').split(','))      # experiments: 'cin-cout-stride-hasresidual' 1x1 shapes kept on the library
+_INPLACE = os.environ.get('WD_SPLIT_INPLACE', '1') != '0'      # experiments: 0 = block outputs in fresh buffers instead of the residual's
+SPLIT_PARTS = set(os.environ.get('WD_SPLIT_PARTS', 'conv1x1,conv3x3,head,fc').split(','))     # experiments: which layer families use the kernel
+
+
+def _split_ok(cin, cout, part='conv1x1'):
+    return SPLIT_GEMM and part in SPLIT_PARTS and cin % 64 == 0 and cout % 32 == 0
 
 
 class _PackedSplit:
@@ -88,7 +93,8 @@ class Conv1x1(nn.Module):
         self._split = _PackedSplit()
 
     def forward(self, x, relu=False, residual=None, stride=1):
-        if not torch.is_grad_enabled() and x.is_cuda and _split_ok(self.weight.shape[1], self.weight.shape[0]):
+        skip = '%d-%d-%d-%d' % (self.weight.shape[1], self.weight.shape[0], stride, 0 if residual is None else 1) in _SKIP
+        if not skip and not torch.is_grad_enabled() and x.is_cuda and _split_ok(self.weight.shape[1], self.weight.shape[0]):
             # split-operand kernel: the strided shortcut reads its pixels in place (no gathered copy), the residual is added in the epilogue
             # and the block output lands in the residual's buffer (dead after this block), as on the library path
             pw = self._split.get(self.weight)
@@ -101,7 +107,7 @@ class Conv1x1(nn.Module):
             if residual is not None:
                 r = residual if residual.is_contiguous(memory_format=torch.channels_last) else residual.contiguous(memory_format=torch.channels_last)
                 r = r.permute(0, 2, 3, 1).reshape(n * h * w, cout)
-            y = ops.gemm_split(a, pw, cout, self.bias, r, relu, out=r)
+            y = ops.gemm_split(a, pw, cout, self.bias, r, relu, out=r if _INPLACE else None)
             return y.view(n, h, w, cout).permute(0, 3, 1, 2)
         if stride != 1:
             x = x[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)
@@ -153,7 +159,7 @@ class ConvBN(nn.Module):
 
     def forward(self, x, relu=False):
         if (not torch.is_grad_enabled() and x.is_cuda and self.groups == 1 and self.weight.shape[2] in (1, 3)
-                and _split_ok(self.weight.shape[1], self.weight.shape[0])):
+                and _split_ok(self.weight.shape[1], self.weight.shape[0], 'conv3x3')):
             # dense 3x3 (FPN output convs, RPN conv): implicit GEMM over (tap, channel) on the split-operand kernel, bias + ReLU fused
             return ops.conv_split(x, self._split.get(self.weight), self.weight.shape[0], self.weight.shape[2], self.stride, self.pad,
                                   self.bias, None, relu)
@@ -406,7 +412,7 @@ class BoxHead(nn.Module):
     def forward(self, x):
         train = torch.is_grad_enabled()
         for li, (conv, norm) in enumerate(zip(self.convs, self.norms)):
-            if not train and x.is_cuda and _split_ok(256, 256):
+            if not train and x.is_cuda and _split_ok(256, 256, 'head'):
                 x = ops.conv_split(x, self._split[li].get(conv.weight), 256, 3, 1, 1)
             elif train and ops.SPLIT_TRAIN and x.is_cuda and _split_ok(256, 256) and x.shape[0] > 0:
                 x = ops.ConvSplitFn.apply(x, conv.weight, None, 1, 1, False)
@@ -425,12 +431,28 @@ class BoxHead(nn.Module):
         flat = x.permute(0, 2, 3, 1).reshape(r, -1)           # NHWC flatten, a view
         if train:
             h = F.relu(F.linear(flat, self.fc1_weight, self.fc1_bias))
-        elif x.is_cuda and _split_ok(self.fc1_weight.shape[1], self.fc1_weight.shape[0]):
+        elif x.is_cuda and _split_ok(self.fc1_weight.shape[1], self.fc1_weight.shape[0], 'fc'):
             # 12544 -> 1024 on the split-operand kernel, K cut into slices (32 output tiles would leave 7/8 of the chip idle)
             h = ops.gemm_split(flat if flat.is_contiguous() else flat.contiguous(), self._split_fc.get(self.fc1_weight), self.fc1_weight.shape[0],
                                self.fc1_bias, None, True)
         else:
             h = ops.gemm_nt(flat, self.fc1_weight, self.fc1_bias, None, True)
+        nc1 = self.cls_weight.shape[0]
+        if not train and x.is_cuda and nc1 + 4 <= 32 and _split_ok(1024, 32, 'fc'):
+            # class scores and box deltas as ONE split-operand GEMM on the concatenated (zero-padded to 32 rows) predictor weights: one launch
+            # (+ the K-slice sum) instead of two skinny library GEMMs whose split-K kernels accumulate with float atomics - run-to-run
+            # identical scores also with other kernels in flight (tests/test_gpu_e2e.py: two pipelines on two streams)
+            key = (self.cls_weight._version, self.box_weight._version, self.cls_bias._version, self.box_bias._version, self.cls_weight.device)
+            if getattr(self, '_pred_key', None) != key:
+                wcat = torch.zeros(32, 1024, device=h.device)
+                wcat[:nc1] = self.cls_weight.detach()
+                wcat[nc1:nc1 + 4] = self.box_weight.detach()
+                bcat = torch.zeros(32, device=h.device)
+                bcat[:nc1] = self.cls_bias.detach()
+                bcat[nc1:nc1 + 4] = self.box_bias.detach()
+                self._pred_packed, self._pred_bias, self._pred_key = ops.split_pack_weight(wcat), bcat, key
+            out = ops.gemm_split(h, self._pred_packed, 32, self._pred_bias, None, False)
+            return out[:, :nc1], out[:, nc1:nc1 + 4]
         logits = F.linear(h, self.cls_weight, self.cls_bias)
         deltas = F.linear(h, self.box_weight, self.box_bias)
         return logits, deltas

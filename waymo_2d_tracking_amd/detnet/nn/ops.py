@@ -342,6 +342,7 @@ def _split_log_end(e0, tag, m, n, k):
 
 
 _SPLIT_WS_BYTES = {}
+_DEBUG_FILL = os.environ.get('WD_DEBUG_FILL') == 'nan'        # diagnostics: NaN-fill fresh outputs / workspaces (anything left unwritten shows)
 
 
 def _split_workspace(m, n, k, device):
@@ -353,7 +354,10 @@ def _split_workspace(m, n, k, device):
         nbytes = _SPLIT_WS_BYTES[key] = int(_lib.lib().wd_gemm_split_workspace(C.c_long(m), C.c_int(n), C.c_int(k)))
     if nbytes == 0:
         return None, 0
-    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if _DEBUG_FILL:
+        ws.view(torch.float32).fill_(float('nan'))
+    return ws, nbytes
 
 
 def split_pack_weight(weight, transpose=False):
@@ -385,6 +389,8 @@ def gemm_split(a, packed, n, bias=None, residual=None, relu=False, out=None):
     assert a.dtype == torch.float32 and a.stride(1) == 1
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        if _DEBUG_FILL:
+            out.fill_(float('nan'))
     assert out.is_contiguous() and (residual is None or residual.is_contiguous())
     ws, ws_bytes = _split_workspace(m, n, k, a.device)
     ev = _split_log_begin()
@@ -401,6 +407,8 @@ def conv_split(x, packed, n_out, ksize, stride=1, pad=0, bias=None, residual=Non
     b, c, h, w = x.shape
     ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
     out = torch.empty((b, n_out, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if _DEBUG_FILL:
+        out.fill_(float('nan'))
     if residual is not None:
         residual = _nhwc(residual)
     ws, ws_bytes = _split_workspace(b * ho * wo, n_out, ksize * ksize * c, x.device)
