@@ -810,9 +810,8 @@ Plan pick_plan(long M, int N, int K, bool allow_split) {
     const int nk_all = K / 32;
     Plan best{5, 1};
     double best_t = 1e30;
-    // MT = 6 fits the ring kernel's 256 registers but measured slower per row block (box-head conv: one round of 256 tiles 297 us against 274 us for
-    // 1.2 rounds of MT = 5): offered only when forced
-    const int mt_max = (kernel_choice() == 0 && forced_mt == 6) ? 6 : 5;
+    // measured cost per row block and K step relative to MT = 4 / 5 (box-head conv 49000 x 256 x 2304, tools/conv_split_one.py): MT = 3 and MT = 6 +24 %
+    const int mt_max = kernel_choice() == 0 ? 6 : 5;            // the ring kernel fits 6 row blocks in 256 registers
     // Tile heights of 2 and 3 row blocks (64 / 96 rows) are NOT offered (only when forced with WD_SPLIT_MT).  Round-5 finding (tools/diag_victim.py,
     // tools/diag_two_models.py, tools/diag_canary.py): while such a launch is in flight, launches of the round-1 deformable kernel
     // (deform_conv3x3_kernel<64, true>) and of the grouped 3x3 kernel on ANOTHER stream return a few hundred slightly wrong outputs each (196 of 200
@@ -830,7 +829,8 @@ Plan pick_plan(long M, int N, int K, bool allow_split) {
             const int per = (nk_all + sk - 1) / sk;
             if (sk > 1 && (per < 3 || (long)(sk - 1) * per >= nk_all)) continue;
             const long rounds = (tiles * sk + 255) / 256;
-            double t = rounds * (mt * per * 0.52 + 2.0 + mt);
+            const double eff = (mt == 4 || mt == 5) ? 1.0 : 1.24;
+            double t = rounds * (mt * per * 0.52 * eff + 2.0 + mt);
             if (sk > 1) t += 3.0 + (double)(sk + 1) * M * N * 4.0 / 4.0e6;
             if (t < best_t * 0.97) { best_t = t; best = Plan{mt, sk}; }      // ties to the larger tile / fewer slices
         }
