@@ -193,9 +193,16 @@ def test_launcher_environment_and_refusal(tmp_path):
     assert all(e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and e['PATH'] == '/usr/bin' for e in envs)
     # N > 1: every rank gets its own MIOpen user database / cache and TunableOp result file (8 ranks in find mode on a fresh box
     # must not write one sqlite file); a location the user exported wins; one rank keeps the library defaults
-    dirs = [(e['MIOPEN_USER_DB_PATH'], e['MIOPEN_CUSTOM_CACHE_DIR'], e['WT_TUNABLEOP_OUT']) for e in
-            L.rank_environments(4, 23456, base_env={}, scratch=str(tmp_path / 'cache'))]
-    assert len({d[0] for d in dirs}) == 4 and len({d[2] for d in dirs}) == 4 and all(os.path.isdir(d[0]) and os.path.isdir(d[1]) for d in dirs)
+    envs4 = L.rank_environments(4, 23456, base_env={}, scratch=str(tmp_path / 'cache'))
+    dirs = [(e['MIOPEN_USER_DB_PATH'], e['MIOPEN_CUSTOM_CACHE_DIR'], e['WT_TUNABLEOP_OUT']) for e in envs4]
+    assert len({d[0] for d in dirs}) == 4 and len({d[2] for d in dirs}) == 4
+    assert not os.path.exists(tmp_path / 'cache')                  # building the environments has no side effects ...
+    for e in envs4:
+        L.prepare_rank_caches(e, scratch=str(tmp_path / 'cache'))  # ... the launcher creates the locations, private to this user
+    assert all(os.path.isdir(d[0]) and os.path.isdir(d[1]) for d in dirs)
+    assert os.stat(tmp_path / 'cache').st_mode & 0o077 == 0 and os.stat(tmp_path / 'cache').st_uid == os.getuid()
+    assert L.prepare_rank_caches({'MIOPEN_USER_DB_PATH': str(tmp_path / 'users' / 'db')}, scratch=str(tmp_path / 'cache')) == 0
+    assert not os.path.exists(tmp_path / 'users')                  # a location outside the launcher's root is never touched
     kept = L.rank_environments(2, 23456, base_env={'MIOPEN_USER_DB_PATH': '/x', 'OMP_NUM_THREADS': '3'}, scratch=str(tmp_path / 'cache'))
     assert all(e['MIOPEN_USER_DB_PATH'] == '/x' and e['OMP_NUM_THREADS'] == '3' for e in kept)
     assert 'MIOPEN_USER_DB_PATH' not in L.rank_environments(1, 23456, base_env={})[0]
@@ -214,6 +221,11 @@ def test_launcher_environment_and_refusal(tmp_path):
     assert open(os.path.join(dest['MIOPEN_USER_DB_PATH'], 'gfx950.udb.txt')).read() == 'find results'
     (home / '.config' / 'miopen' / 'gfx950.udb.txt').write_text('newer')
     assert L.seed_rank_cache(dest, home=str(home)) == 0 and open(os.path.join(dest['MIOPEN_USER_DB_PATH'], 'gfx950.udb.txt')).read() == 'find results'
+    # the launchers refresh a location THEY seeded when the source has changed since (re-tuned default database)
+    os.utime(home / '.config' / 'miopen' / 'gfx950.udb.txt', (2e9, 2e9))
+    assert L.seed_rank_cache(dest, home=str(home), refresh=True) == 1
+    assert open(os.path.join(dest['MIOPEN_USER_DB_PATH'], 'gfx950.udb.txt')).read() == 'newer'
+    assert L.seed_rank_cache(dest, home=str(home), refresh=True) == 0
     assert L.seed_rank_cache({'MIOPEN_USER_DB_PATH': str(tmp_path / 'x')}, home=str(tmp_path / 'nohome')) == 0
     # WT_FORCE_DIST=1 without a launcher: only the rendezvous variables are adopted, a user's thread count survives
     saved = dict(os.environ)

@@ -39,6 +39,21 @@ int ensure_device() {
     return WT_OK;
 }
 
+int device_index() {
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+
+int device_cus() {
+    static int cus[MAX_DEVICES] = {};
+    const int dev = device_index();
+    if (dev >= 0 && dev < MAX_DEVICES && cus[dev] > 0) return cus[dev];
+    hipDeviceProp_t prop;
+    if (dev < 0 || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (dev < MAX_DEVICES) cus[dev] = prop.multiProcessorCount;
+    return prop.multiProcessorCount;
+}
+
 }  // namespace wt
 
 extern "C" {

@@ -13,6 +13,17 @@ void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 int ensure_device();               // WT_OK when a gfx950 device is current and usable
 
+// Launcher state that belongs to a DEVICE, not to the process (a process may drive more than one GPU): the CU count the grids are sized from
+// and "has this launcher raised its kernels' dynamic-LDS limit on this device yet" (hipFuncSetAttribute is per device).
+constexpr int MAX_DEVICES = 32;
+int device_index();                // hipGetDevice; -1 when it fails
+int device_cus();                  // CU count of the current device (cached per device, safe inside a stream capture after the first call); 0 = unknown
+struct OncePerDevice {
+    bool done[MAX_DEVICES] = {};   // written with the same value by every thread that races here: the guarded calls are idempotent
+    bool needed(int dev) const { return dev < 0 || dev >= MAX_DEVICES || !done[dev]; }
+    void mark(int dev) { if (dev >= 0 && dev < MAX_DEVICES) done[dev] = true; }
+};
+
 #define WT_HIP(call)                                                   \
     do {                                                               \
         hipError_t e__ = (call);                                       \

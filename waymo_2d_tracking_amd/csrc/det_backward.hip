@@ -108,8 +108,10 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n
             const float y = rsh + (float)ph * bin_h + ((float)iy + .5f) * bin_h / (float)gh;
             int lo, hi; float wl, wh;
             if (!roi_axis_sample(y, H, lo, hi, wl, wh)) continue;
-            wy[ph][lo - r0] += wl;
-            wy[ph][hi - r0] += wh;
+            // the footprint bound and the sample coordinate are two float expressions: a sample that rounds across the last row can only carry
+            // weight 0 there (its y is within an ulp of the integer), but the index is still kept inside the table
+            if ((unsigned)(lo - r0) < (unsigned)nr) wy[ph][lo - r0] += wl;
+            if ((unsigned)(hi - r0) < (unsigned)nr) wy[ph][hi - r0] += wh;
         }
     } else if (threadIdx.x >= 64 && threadIdx.x < 64 + PP) {
         const int pw = threadIdx.x - 64;
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(256) void roi_pool_fpn_bwd_kernel(LevelsW lv, int n
             const float x = rsw + (float)pw * bin_w + ((float)ix + .5f) * bin_w / (float)gw;
             int lo, hi; float wl, wh;
             if (!roi_axis_sample(x, W, lo, hi, wl, wh)) continue;
-            wx[pw][lo - c0] += wl;
-            wx[pw][hi - c0] += wh;
+            if ((unsigned)(lo - c0) < (unsigned)nc) wx[pw][lo - c0] += wl;
+            if ((unsigned)(hi - c0) < (unsigned)nc) wx[pw][hi - c0] += wh;
         }
     }
     __syncthreads();

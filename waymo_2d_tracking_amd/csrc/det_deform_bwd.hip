@@ -870,12 +870,9 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
     const Geo geo = make_geo(h, w, stride);
     const int ntiles = geo_tiles(geo, batch);
     const int items = ntiles * groups;
-    static const int cus = [] {                             // once per process (one process per GPU); thread-safe initialisation
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        return prop.multiProcessorCount;
-    }();
+    const int cus = wt::device_cus();                       // per device: a process that drives a second GPU sizes its grid from THAT one
+    static wt::OncePerDevice attr32, attr16;
+    const int dev = wt::device_index();
     if (cus <= 0) { wt::set_error("wd_deform_dxoff_f32: cannot read the device properties"); return WT_ERR_HIP; }
     int nwg = 2 * cus;                                       // two workgroups (77 KB of LDS, 6 waves each) per CU, all resident
     if (const char* e = getenv("WD_DXOFF_WGS")) nwg = atoi(e);
@@ -887,9 +884,11 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
     if (far_chunks > groups) far_chunks = groups;
     const int naux = 4 * cus;                                // blocks that zero dX and pack the weights, in the launch that builds the tables
     if (cg == 32) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(deform_dxoff_kernel<32>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dxoff_smem_bytes<32>());
-        WT_HIP(attr);
+        if (attr32.needed(dev)) {
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_dxoff_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)dxoff_smem_bytes<32>()));
+            attr32.mark(dev);
+        }
         hipLaunchKernelGGL(deform_bwd_tables_kernel<32>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, geo, tables, weight, c,
                            packed_weight, dx, doffset);
         hipLaunchKernelGGL(deform_dxoff_kernel<32>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<32>(), st, x, dy, y_act, scale, packed_weight, tables, batch, geo,
@@ -897,9 +896,11 @@ int wd_deform_dxoff_f32(const float* x, const float* offset, const float* dy, co
         hipLaunchKernelGGL(deform_bwd_far_kernel<32>, dim3((unsigned)ntiles, (unsigned)far_chunks), dim3(256), 0, st, x, dy, y_act, scale, packed_weight, tables, batch, geo, c,
                            dx, doffset);
     } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(deform_dxoff_kernel<16>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dxoff_smem_bytes<16>());
-        WT_HIP(attr);
+        if (attr16.needed(dev)) {
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_dxoff_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)dxoff_smem_bytes<16>()));
+            attr16.mark(dev);
+        }
         hipLaunchKernelGGL(deform_bwd_tables_kernel<16>, dim3((unsigned)(ntiles + naux)), dim3(256), 0, st, offset, batch, geo, tables, weight, c,
                            packed_weight, dx, doffset);
         hipLaunchKernelGGL(deform_dxoff_kernel<16>, dim3((unsigned)nwg), dim3(384), dxoff_smem_bytes<16>(), st, x, dy, y_act, scale, packed_weight, tables, batch, geo,

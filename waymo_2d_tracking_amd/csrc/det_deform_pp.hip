@@ -686,8 +686,8 @@ static int scratch_table(size_t bytes, hipStream_t stream, void** out) {
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
                         const float* bias, int relu, int batch, int h, int w, int c, int cg, int stride, hipStream_t stream, float* y,
                         const void* table) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static wt::OncePerDevice attr;
+    if (const int dev = wt::device_index(); attr.needed(dev)) {
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<32>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<32>()));
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<16>),
@@ -696,7 +696,7 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<32, pp::PS_WIDE, 1>()));
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(deform_conv3x3_pp_kernel<16, false, pp::PS_WIDE, 1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::smem_bytes<16, pp::PS_WIDE, 1>()));
-        attr_set = true;
+        attr.mark(dev);
     }
     const int ho = (h + 2 - 3) / stride + 1, wo = (w + 2 - 3) / stride + 1;
     const int items = c / pp::CH;
@@ -716,12 +716,7 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
         WT_HIP(hipGetLastError());
         table = scratch;
     }
-    static int n_cu = 0;                                            // queried once (not inside a stream capture)
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = wt::device_cus() > 0 ? wt::device_cus() : 256;  // cached per device (the first call is not inside a stream capture)
     int nsplit = n_cu / items;
     static const int nsplit_env = getenv("WD_PP_NSPLIT") ? atoi(getenv("WD_PP_NSPLIT")) : 0;    // experiments: fewer workgroups per item
     if (nsplit_env > 0 && nsplit_env < nsplit) nsplit = nsplit_env;

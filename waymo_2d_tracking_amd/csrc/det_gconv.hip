@@ -137,18 +137,14 @@ __global__ __launch_bounds__(256, 2) void grouped_conv3x3_c8_kernel(const float*
 // Plain grouped 3x3 conv, 8 channels per group, stride 1, pad 1 (called by wd_deform_conv3x3_f32 when offset == NULL).
 int wd_grouped_conv3x3_c8_launch(const float* x, const float* packed_weight, const float* scale, const float* bias, int relu,
                                  int batch, int h, int w, int c, hipStream_t stream, float* y) {
-    static int n_cu = 0;
-    static bool attr_set = false;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = wt::device_cus() > 0 ? wt::device_cus() : 256;
+    static wt::OncePerDevice attr;
+    const int dev = wt::device_index();
     const size_t smem = (size_t)gc::PATCH_F * sizeof(float);
-    if (!attr_set) {
+    if (attr.needed(dev)) {
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_conv3x3_c8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));
-        attr_set = true;
+        attr.mark(dev);
     }
     const int halves = c / gc::CH;
     const long ntiles = (long)batch * ((h + gc::TS - 1) / gc::TS) * ((w + gc::TS - 1) / gc::TS);

@@ -398,10 +398,10 @@ extern "C" int wd_gemm_nt_ws_f32(const float* A, const float* Bt, const float* b
     hipStream_t stream = (hipStream_t)stream_;
     const int splitk = (int)(need / ((size_t)M * N * sizeof(float)));
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static wt::OncePerDevice attr;
+    if (const int dev = wt::device_index(); attr.needed(dev)) {
         WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr_set = true;
+        attr.mark(dev);
     }
     hipLaunchKernelGGL(gemm_nt_v2_kernel, dim3((unsigned)(tiles * splitk)), dim3(256), 65536, stream, A, Bt, M, N, K, splitk,
                        (float*)workspace);

@@ -432,6 +432,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #pragma unroll
         for (int i = 0; i < MT; ++i) a_store_val(BUF, i, p1[i]);
     }
+#ifdef WD_SPLIT_ADEEP
+    float2 aahead[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) aahead[i] = a_fetch(3, i);
+#endif
     long long t_main = 0;
     if (p.stamps) t_main = __builtin_amdgcn_s_memtime();      // (an SMEM op: kept in front of the lgkmcnt(0) below, see the loop's counted waits)
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -461,6 +466,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #elif WD_ABL & 1
 #define SPLIT_ROW(i_)                                                                                         \
     if ((i_) < MT) { a_store_row(wr, (i_)); }
+#elif defined(WD_SPLIT_ADEEP)
+    // A rows two K steps ahead (a second register set): araw = step kt + 2 (split now), aahead = step kt + 3, reload with step kt + 4
+#define SPLIT_ROW(i_)                                                                                         \
+    if ((i_) < MT) { a_store_row(wr, (i_)); araw[(i_)] = aahead[(i_)]; aahead[(i_)] = a_fetch(kt + 4, (i_)); }
 #else
 #define SPLIT_ROW(i_)                                                                                         \
     if ((i_) < MT) { a_store_row(wr, (i_)); a_load_row(kt + 3, (i_)); }

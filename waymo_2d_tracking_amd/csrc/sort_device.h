@@ -297,8 +297,9 @@ __device__ __forceinline__ void track_init(const TrackerMem& M, int slot, const 
 // workgroup barrier and are woken for the phases that are plain data parallelism over the n x m cost matrix - today Munkres step 6
 // (37 % of the tracker's cycles at one segment): wave w takes the columns c = w (mod 4) of every row, the four partial minima and the
 // partial zero bitmaps meet in LDS.  Elementwise the same float operations in the same order: identical matrices, identical bitmaps.
-// Protocol: wave 0 fills the job, sets cmd, wsync() (wakes the helpers), everybody runs help_step6_share (two more barriers inside),
-// wave 0 resets cmd.  Every other wsync() of the single-wave code wakes the helpers for a no-op round trip (cmd = NOP).
+// Protocol: wave 0 fills the job, sets cmd and reaches a workgroup barrier (__syncthreads - the helpers sleep at theirs, so this is what
+// wakes them; wsync() is a wave-level fence + wave barrier and wakes nobody), everybody runs the share (help_step6_share: two more
+// workgroup barriers inside), wave 0 resets cmd.  The single-wave code between jobs uses wsync() only, so the helpers sleep through it.
 struct HelpJob {
     int cmd;                       // HELP_NOP / HELP_STEP6 / HELP_EXIT
     int n, m, ld, changed;

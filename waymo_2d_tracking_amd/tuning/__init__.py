@@ -33,9 +33,12 @@ def enable_gemm_tuning(online=None, max_tuning_ms=15, max_iterations=30):
     # new selections of this process go to a scratch file (never into the package)
     t.set_filename(os.environ.get('WT_TUNABLEOP_OUT', os.path.join(tempfile.gettempdir(), 'wt_tunableop_%d.csv' % os.getpid())))
     loaded = False
-    if os.path.exists(PACKAGED):
+    # WT_TUNABLEOP_IN: another selection file instead of the packaged one ('' = none, start from the library defaults) - A/B experiments
+    # (tools/tune_gemms_long.sh) select their file here and never touch the packaged one
+    source = os.environ.get('WT_TUNABLEOP_IN', PACKAGED)
+    if source and os.path.exists(source):
         try:
-            loaded = bool(t.read_file(PACKAGED))
+            loaded = bool(t.read_file(source))
         except Exception:
             loaded = False
     t.tuning_enable(bool(online))
