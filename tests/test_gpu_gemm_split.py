@@ -220,3 +220,38 @@ def test_split_gemm_rejects_unsupported_shapes(ops):
     with pytest.raises(WaymoTrackError):
         ops.gemm_split(torch.randn(64, 128, device='cuda'), pw, 48)         # N % 32 != 0
     del a
+
+
+def test_whole_detector_split_graph_vs_exact_f32_graph(monkeypatch):
+    """whole-detector boxes of the split-operand graph against the all-exact-f32 graph (hipBLASLt / MIOpen f32).  Neither is the truth -
+    both are float32 evaluations; the library graph differs from ITSELF run twice by up to 2 - 4 float32 spacings of a pixel coordinate (split-K atomics),
+    and the split graph stays at that floor.  Full size (1920 x 1280, three seeds): profiles/r05_split_box_drift.txt (tools/split_box_drift.py) - same-proposal
+    boxes <= 2.4e-4 px vs an exact-vs-exact floor of 1.2e-4 .. 2.4e-4 px, scores <= 2.4e-7, FPN features <= 3.7e-6 relative, no unmatched detection.
+    (A bound of 1e-5 px is below the float32 spacing of the coordinates themselves: 6.1e-5 px at 1000 px.)  Here: 640 x 448, gates 8x above the measured values."""
+    from waymo_2d_tracking_amd.detnet.nn import cascade_rcnn
+    from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
+    net = Detectron2Det(seed=2).eval().cuda().model
+    g = torch.Generator().manual_seed(102)
+    img = torch.randint(0, 256, (1, 3, 448, 640), generator=g).float().cuda()
+
+    def run(split, proposals=None):
+        monkeypatch.setattr(cascade_rcnn, 'SPLIT_GEMM', split)
+        inter = {}
+        out = net(img, proposals=proposals, intermediates=inter)
+        return out, inter
+
+    (eb, es, ec), ei = run(False)
+    (sb, ss, sc), si = run(True)
+    for a, b in zip(si['feats'], ei['feats']):
+        assert float((a - b).abs().max() / b.abs().max()) <= 3e-5
+    n = int(ei['n_proposals'].item())
+    assert n > 100
+    props = ei['proposals'][:n].clone()
+    _, pe = run(False, props)
+    _, ps = run(True, props)
+    assert float((ps['boxes'] - pe['boxes']).abs().max()) <= 2e-3                     # pixels
+    assert float((ps['scores'] - pe['scores']).abs().max()) <= 2e-6
+    # end to end: the same detections (RPN top-k / NMS decisions included) up to near-ties
+    assert abs(sb.shape[0] - eb.shape[0]) <= 2 and eb.shape[0] > 0
+    d = (sb.double()[:, None, :] - eb.double()[None, :, :]).abs().amax(-1).min(dim=1).values
+    assert float((d < 2e-3).double().mean()) >= 0.97

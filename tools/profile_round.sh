@@ -24,4 +24,9 @@ WT_FORCE_DIST=1 python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/e
 bash tools/hbm_roofline.sh > /dev/null 2>&1; cp gpurun_out/hbm_roofline/summary.json $OUT/hbm_rooflines.json
 bash tools/pmc_traffic.sh > /dev/null 2>&1; cp gpurun_out/prof_e2e/pmc_traffic.json $OUT/e2e_pmc_traffic.json 2>/dev/null
 bash tools/jpeg_profile.sh 20 > /dev/null 2>&1; cp gpurun_out/jpeg/per_image.txt $OUT/jpeg_per_kernel.txt; cp gpurun_out/jpeg/bench.txt $OUT/jpeg_single_call_vs_pil.txt
+# round 5: the split-operand kernel - counters, compile-time ablations, per-shape time / error table, whole-detector drift
+bash tools/pmc_split.sh 9600 1024 1024 1 $OUT/split_pmc.txt > /dev/null 2>&1
+bash tools/split_ablation.sh "9600 1024 1024" > $OUT/split_ablation.txt 2>&1
+python3 tools/gemm_split_bench.py --json $OUT/split_gemm_bench.json > /dev/null 2>&1
+python3 tools/split_box_drift.py --out $OUT/split_box_drift.txt > /dev/null 2>&1
 for f in $OUT/*_bench_line.json; do echo $f; tail -1 $f | cut -c1-170; done

@@ -301,6 +301,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_k64_kernel(const Split
 // complete and visible for the whole of step j: the last slots of a step prefetch the next step's fragments ACROSS the barrier, whose
 // wait is a counted lgkmcnt (the LDS writes are older than the MT outstanding prefetch reads).  One barrier per 2 x 6 MT MFMAs, no drain.
 // A rows are staged as float2 per thread (160 rows x 32 floats / 512 threads = 5 float2), three ds_write_b32 per row block.
+// A rows fetched two K steps ahead of their split (a second register set; MT = 6 still fits 256 VGPRs without scratch).  Measured on MI355X,
+// graph replay, same box (profiles/r05_split_adeep.txt): res4 1x1 116.0 -> 109.3 us, box-head 3x3 347.1 -> 340.6 us, FPN p2 3x3 998 -> 965 us, res3 equal.
+// -DWD_SPLIT_ADEEP=0 builds the one-step-ahead loop it replaced.
+#ifndef WD_SPLIT_ADEEP
+#define WD_SPLIT_ADEEP 1
+#endif
 #ifndef WD_ABL
 #define WD_ABL 0
 #endif
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #pragma unroll
         for (int i = 0; i < MT; ++i) a_store_val(BUF, i, p1[i]);
     }
-#ifdef WD_SPLIT_ADEEP
+#if WD_SPLIT_ADEEP
     float2 aahead[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) aahead[i] = a_fetch(3, i);
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #elif WD_ABL & 1
 #define SPLIT_ROW(i_)                                                                                         \
     if ((i_) < MT) { a_store_row(wr, (i_)); }
-#elif defined(WD_SPLIT_ADEEP)
+#elif WD_SPLIT_ADEEP
     // A rows two K steps ahead (a second register set): araw = step kt + 2 (split now), aahead = step kt + 3, reload with step kt + 4
 #define SPLIT_ROW(i_)                                                                                         \
     if ((i_) < MT) { a_store_row(wr, (i_)); araw[(i_)] = aahead[(i_)]; aahead[(i_)] = a_fetch(kt + 4, (i_)); }
