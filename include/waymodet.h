@@ -74,6 +74,20 @@ size_t wd_gemm_split_packed_bytes(int N, int K);
 int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* stream);
 /* the same for any 2-D view: element (n, k) = w[n * stride_n + k * stride_k] (the transpose of a weight for the backward-data GEMM of training) */
 int wd_gemm_split_pack_weight_strided(const float* w, int N, int K, long stride_n, long stride_k, void* packed, void* stream);
+/* Many weights in ONE launch (a training step re-packs every trainable weight after the optimizer step, in the forward and the backward-data
+ * orientation).  Descriptors live in DEVICE memory.  A source is addressed through strides, so a convolution weight (N, C, ks, ks) is read where it
+ * lies: element (n, k) with k = (kh * ks + kw) * C + c is src[n * s_n + c * s_c + kh' * s_kh + kw' * s_kw], (kh', kw') = (ks-1-kh, ks-1-kw) when flip
+ * (the weight of the backward-data convolution: flipped taps, channel roles swapped through s_n / s_c).  A 2-D (N, K) weight: C = K, ksize = 1.
+ * K % 64 == 0, C % 8 == 0.  first_block = running sum of blocks(i) = ceil(ceil32(N_i) * (K_i / 8) / 256) over the descriptors before i (ascending);
+ * total_blocks = the sum over all.  dst: wd_gemm_split_packed_bytes(N, K) bytes, 16-byte aligned. */
+typedef struct WdSplitPackDesc {
+    const float* src;
+    void* dst;
+    long s_n, s_c, s_kh, s_kw;
+    long first_block;
+    int N, K, C, ksize, flip, reserved;
+} WdSplitPackDesc;
+int wd_gemm_split_pack_batch(const WdSplitPackDesc* descs_device, int count, long total_blocks, void* stream);
 /* Shapes with few output tiles (FPN p5 / p6 convolutions, the box-head FC) are cut into K slices whose partial tiles meet in `workspace`
  * (wd_gemm_split_workspace(M, N, K) bytes; M = batch * Ho * Wo, K = ksize^2 * C for the convolution) and are summed in slice order by a second
  * launch: deterministic.  workspace may be NULL / smaller: the call then runs unsliced. */

@@ -255,3 +255,52 @@ def test_whole_detector_split_graph_vs_exact_f32_graph(monkeypatch):
     assert abs(sb.shape[0] - eb.shape[0]) <= 2 and eb.shape[0] > 0
     d = (sb.double()[:, None, :] - eb.double()[None, :, :]).abs().amax(-1).min(dim=1).values
     assert float((d < 2e-3).double().mean()) >= 0.97
+
+
+def test_cached_batch_pack_equals_single_packs_and_follows_the_weight(ops):
+    """split_pack_cached (training): packs live on the weight tensor, follow its version counter, and the sweep after an in-place update re-packs every
+    used weight in one wd_gemm_split_pack_batch launch - bit-identical to wd_gemm_split_pack_weight on the materialised (permuted / flipped /
+    transposed) copy.  A new tensor at a recycled address never hits the old pack."""
+    torch.manual_seed(5)
+    lin = torch.randn(128, 192, device='cuda')
+    conv = torch.randn(64, 128, 3, 3, device='cuda')
+    one = torch.randn(128, 64, 1, 1, device='cuda')
+    cl = torch.randn(64, 64, 3, 3, device='cuda').contiguous(memory_format=torch.channels_last)      # strides are honoured
+
+    def reference(w, kind):
+        if kind == 'T':
+            return ops.split_pack_weight(w, transpose=True)
+        if kind == 'dx':
+            return ops.split_pack_weight(w.flip(2, 3).permute(1, 0, 2, 3).contiguous())
+        return ops.split_pack_weight(w.contiguous())
+
+    cases = [(lin, 'fwd'), (lin, 'T'), (conv, 'fwd'), (conv, 'dx'), (one, 'fwd'), (one, 'dx'), (cl, 'fwd'), (cl, 'dx')]
+    for w, kind in cases:
+        assert torch.equal(ops.split_pack_cached(w, kind), reference(w, kind)), kind
+    first = [ops.split_pack_cached(w, kind) for w, kind in cases]
+    assert all(a.data_ptr() == ops.split_pack_cached(w, kind).data_ptr() for a, (w, kind) in zip(first, cases))          # cached: the same buffer
+    # in-place update of every weight (an optimizer step): the first request re-packs all of them in one launch
+    for w in (lin, conv, one, cl):
+        w.mul_(1.5).add_(0.01)
+    before = len(ops._PACK_REGISTRY)
+    got = ops.split_pack_cached(lin, 'fwd')
+    assert torch.equal(got, reference(lin, 'fwd'))
+    for w, kind in cases:
+        e = w._wd_split_packs[kind]
+        assert e.version == w._version and torch.equal(e.packed, reference(w, kind)), kind      # already fresh: packed by the sweep
+    assert len(ops._PACK_REGISTRY) <= before
+    # a used GEMM through the cached pack
+    a = torch.randn(70, 192, device='cuda')
+    y = ops.gemm_split(a, ops.split_pack_cached(lin), 128)
+    assert torch.equal(y, ops.gemm_split(a, ops.split_pack_weight(lin), 128))
+    assert float((y.double() - a.double() @ lin.double().t()).abs().max()) <= 1e-4
+    # recycled address: a new weight of the same shape where a freed one lay must not see the old planes
+    tmp = torch.randn(96, 128, device='cuda')
+    ptr = tmp.data_ptr()
+    ops.split_pack_cached(tmp)
+    del tmp
+    again = torch.randn(96, 128, device='cuda')
+    if again.data_ptr() == ptr:
+        assert torch.equal(ops.split_pack_cached(again), ops.split_pack_weight(again))
+    with pytest.raises(ValueError):
+        ops.split_pack_cached(torch.randn(64, 96, device='cuda'))                  # K % 64 != 0

@@ -20,6 +20,20 @@ for r in sel:
 tot = sum(v[1] for v in acc.values())
 wall = (int(sel[-1]['End_Timestamp']) - int(sel[0]['Start_Timestamp'])) / 1e6
 print('3 steps: kernel time %.1f ms/step, wall %.1f ms/step' % (tot / 3, wall / 3))
+# idle time between kernels (the host not keeping up / host synchronisations): total, and summed by the kernel that ran BEFORE the gap
+end = int(sel[0]['End_Timestamp'])
+gaps = collections.defaultdict(lambda: [0, 0.0])
+idle = 0.0
+for a, b in zip(sel, sel[1:]):
+    end = max(end, int(a['End_Timestamp']))
+    g = (int(b['Start_Timestamp']) - end) / 1e3
+    if g > 0:
+        idle += g
+        key = a['Kernel_Name'][:60] + '  ->  ' + b['Kernel_Name'][:60]
+        gaps[key][0] += 1; gaps[key][1] += g
+print('idle between kernels: %.2f ms/step; by (kernel before -> kernel after), us/step:' % (idle / 3e3))
+for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
+    print('   %8.1f us/step %6.1f gaps/step  %s' % (v[1] / 3, v[0] / 3, k))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])[:70]:
     print('%7.2f ms/step %7.1f calls/step %8.1f us  %s' % (v[1] / 3, v[0] / 3, v[1] / v[0] * 1e3, k))
 PY

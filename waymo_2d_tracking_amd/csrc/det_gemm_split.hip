@@ -792,6 +792,40 @@ __global__ __launch_bounds__(256) void gemm_split_pack_kernel(const float* __res
     dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// Many weights in ONE launch (the training step: every trainable 1x1 / 3x3 / FC weight is re-packed after the optimizer step, forward and
+// backward-data orientation - ~500 launches of ~10 us otherwise).  A descriptor addresses its source through strides, so convolution weights
+// (N, C, ks, ks) are read where they lie (no permute / flip copies): element (n, k), k = (kh * ks + kw) * C + c, = src[n s_n + c s_c + kh' s_kh + kw' s_kw]
+// with (kh', kw') = (ks - 1 - kh, ks - 1 - kw) when `flip` (the backward-data convolution).  Workgroup -> descriptor by binary search over first_block.
+__global__ __launch_bounds__(256) void gemm_split_pack_batch_kernel(const WdSplitPackDesc* __restrict__ descs, int count) {
+    int lo = 0, hi = count - 1;
+    const long blk = blockIdx.x;
+    while (lo < hi) {                                   // last descriptor with first_block <= blk (uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const WdSplitPackDesc d = descs[lo];
+    const long t = (blk - d.first_block) * 256 + threadIdx.x;
+    const int k8 = d.K / 8;
+    const long total = (long)((d.N + 31) / 32) * 32 * k8;
+    if (t >= total) return;
+    const int n = (int)(t / k8), kq = (int)(t - (long)n * k8);
+    const int k = 8 * kq, tap = k / d.C, c = k - tap * d.C;          // 8 consecutive k share a tap (C % 8 == 0)
+    int kh = tap / d.ksize, kw = tap - kh * d.ksize;
+    if (d.flip) { kh = d.ksize - 1 - kh; kw = d.ksize - 1 - kw; }
+    const float* src = d.src + (size_t)n * d.s_n + (size_t)kh * d.s_kh + (size_t)kw * d.s_kw + (size_t)c * d.s_c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = n < d.N ? src[(size_t)e * d.s_c] : 0.f;
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], h[e], m[e], l[e]);
+    const int nt = n >> 5, ks = kq >> 1, ln = (n & 31) + 32 * (kq & 1);
+    uint4* dst = reinterpret_cast<uint4*>(d.dst) + ((size_t)nt * (d.K / 16) + ks) * 192 + ln;
+    dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    dst[64] = make_uint4(m[0], m[1], m[2], m[3]);
+    dst[128] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 // out = act(sum over the K slices in slice order + bias + residual): deterministic, one float4 per thread
 __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float4* __restrict__ part, int splitk, long mn4, int n4, const float4* __restrict__ bias,
                                                                 const float* __restrict__ residual, long ldc, int relu, float* __restrict__ out) {
@@ -975,6 +1009,18 @@ int wd_gemm_split_pack_weight_strided(const float* w, int N, int K, long stride_
 
 int wd_gemm_split_pack_weight(const float* w, int N, int K, void* packed, void* stream_) {
     return wd_gemm_split_pack_weight_strided(w, N, K, (long)K, 1, packed, stream_);
+}
+
+int wd_gemm_split_pack_batch(const WdSplitPackDesc* descs_device, int count, long total_blocks, void* stream_) {
+    WT_TRY(wt::ensure_device());
+    if (count <= 0 || total_blocks <= 0) return WT_OK;
+    if (!descs_device || total_blocks >= (1l << 31)) {
+        wt::set_error("wd_gemm_split_pack_batch: NULL descriptor array or too many workgroups (%ld)", total_blocks);
+        return WT_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(gemm_split_pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream_, descs_device, count);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
 }
 
 /* Bytes of scratch the K-sliced form of a shape wants (0: the shape runs unsliced).  Passing less (or NULL) is legal: the call then runs unsliced. */

@@ -17,7 +17,15 @@ from ... import _lib
 EVENT_LOG = None
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_RAW_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a void*.  The raw accessors skip the torch.cuda.Stream object that
+    torch.cuda.current_stream() builds per call (~2 us of host time on each of the ~1500 launches of a training step)."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -380,6 +388,115 @@ def split_pack_weight(weight, transpose=False):
     _lib.check(lib.wd_gemm_split_pack_weight_strided(_p(w), C.c_int(n), C.c_int(k), C.c_long(w.stride(0)), C.c_long(w.stride(1)), _p(packed), _stream()),
                'wd_gemm_split_pack_weight_strided')
     return packed
+
+
+class _PackEntry:
+    __slots__ = ('ref', 'kind', 'key', 'packed', 'version', 'desc', 'blocks', 'used')
+
+
+_PACK_REGISTRY = []          # every cached pack of the process (the entry holds a weak reference to its weight)
+_PACK_DESC_CACHE = [None, None]      # (ids of the entries of the last batch, its descriptor array on the device)
+_PACK_DESC_FIELDS = ('src', 'dst', 's_n', 's_c', 's_kh', 's_kw', 'first_block', 'N', 'K', 'C', 'ksize', 'flip', 'reserved')     # WdSplitPackDesc
+
+
+def _pack_desc_dtype():
+    import numpy as np
+    return np.dtype([(f, '<u8' if f in ('src', 'dst') else ('<i8' if f in ('s_n', 's_c', 's_kh', 's_kw', 'first_block') else '<i4')) for f in _PACK_DESC_FIELDS])
+
+
+def _new_pack_entry(weight, kind):
+    import weakref
+    w = weight
+    if w.dtype != torch.float32 or not w.is_cuda:
+        raise ValueError('split_pack_cached: float32 weights on the GPU only')
+    if w.dim() == 2:
+        if kind == 'fwd':
+            n, k, sn, sc = w.shape[0], w.shape[1], w.stride(0), w.stride(1)
+        elif kind == 'T':
+            n, k, sn, sc = w.shape[1], w.shape[0], w.stride(1), w.stride(0)
+        else:
+            raise ValueError('split_pack_cached: kind %r needs a convolution weight' % kind)
+        c, ks, skh, skw, flip = k, 1, 0, 0, 0
+    elif w.dim() == 4 and w.shape[2] == w.shape[3]:
+        ks = w.shape[2]
+        skh, skw = w.stride(2), w.stride(3)
+        if kind == 'fwd':
+            n, c, sn, sc, flip = w.shape[0], w.shape[1], w.stride(0), w.stride(1), 0
+        elif kind == 'dx':                  # backward-data convolution: taps flipped, channel roles swapped
+            n, c, sn, sc, flip = w.shape[1], w.shape[0], w.stride(1), w.stride(0), 1
+        else:
+            raise ValueError('split_pack_cached: kind %r needs a 2-D weight' % kind)
+        k = ks * ks * c
+    else:
+        raise ValueError('split_pack_cached: 2-D or square-kernel 4-D weights')
+    nbytes = int(_lib.lib().wd_gemm_split_packed_bytes(C.c_int(n), C.c_int(k)))
+    if nbytes == 0 or c % 8:
+        raise ValueError('split_pack_cached: K must be a multiple of 64 (N=%d K=%d)' % (n, k))
+    e = _PackEntry()
+    e.ref, e.kind = weakref.ref(weight), kind
+    e.key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()))
+    e.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    e.version = -1
+    e.blocks = ((n + 31) // 32 * 32 * (k // 8) + 255) // 256
+    e.desc = (w.data_ptr(), e.packed.data_ptr(), sn, sc, skh, skw, 0, n, k, c, ks, flip, 0)
+    e.used = True
+    return e
+
+
+def _pack_entries(entries):
+    """One launch (wd_gemm_split_pack_batch) that packs every entry's weight as it is NOW."""
+    import numpy as np
+    if not entries:
+        return
+    ids = tuple(id(e) for e in entries)
+    dev = entries[0].packed.device
+    total = sum(e.blocks for e in entries)
+    if _PACK_DESC_CACHE[0] == ids:
+        desc = _PACK_DESC_CACHE[1]
+    else:
+        arr = np.zeros(len(entries), dtype=_pack_desc_dtype())
+        first = 0
+        for i, e in enumerate(entries):
+            arr[i] = e.desc[:6] + (first,) + e.desc[7:]
+            first += e.blocks
+        desc = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+        _PACK_DESC_CACHE[0], _PACK_DESC_CACHE[1] = ids, desc
+    _lib.check(_lib.lib().wd_gemm_split_pack_batch(_p(desc), C.c_int(len(entries)), C.c_long(total), _stream()), 'wd_gemm_split_pack_batch')
+    for e in entries:
+        w = e.ref()
+        e.version = w._version if w is not None else e.version
+
+
+def split_pack_cached(weight, kind='fwd'):
+    """The packed bf16 planes of `weight` for gemm_split / conv_split, cached ON the weight tensor and re-packed when the weight has changed
+    (its autograd version counter: every in-place update - an optimizer step - bumps it).  kind: 'fwd' = the weight as it is (2-D (N, K), or a
+    convolution weight (N, C, ks, ks) read through its strides, no permute copy); 'T' = the transpose of a 2-D weight (backward-data GEMM);
+    'dx' = a convolution weight with flipped taps and swapped channel roles (backward-data convolution).  The first stale weight met after an
+    optimizer step re-packs EVERY cached weight that was used since the previous sweep in ONE launch (wd_gemm_split_pack_batch): a training step of
+    the X-152 detector packs ~250 weights in two orientations - 2.4 ms of 10-us launches plus the permute / flip copies before (rocprof, round 5)."""
+    packs = getattr(weight, '_wd_split_packs', None)
+    if packs is None:
+        packs = {}
+        weight._wd_split_packs = packs               # lives and dies with the tensor object: no stale hit through a recycled address
+    e = packs.get(kind)
+    if e is None or e.key != (weight.data_ptr(), tuple(weight.shape), tuple(weight.stride())) or e.packed.device != weight.device:
+        e = packs[kind] = _new_pack_entry(weight, kind)
+        _PACK_REGISTRY.append(e)
+        _pack_entries([e])
+    elif e.version != weight._version:
+        stale, alive = [], []
+        for q in _PACK_REGISTRY:
+            w = q.ref()
+            if w is None or getattr(w, '_wd_split_packs', {}).get(q.kind) is not q:
+                continue                                 # weight gone, or its entry was replaced
+            alive.append(q)
+            if q.packed.device == e.packed.device and (q is e or (q.used and q.version != w._version)):
+                stale.append(q)
+            q.used = False
+        _PACK_REGISTRY[:] = alive
+        _pack_entries(stale)
+    e.used = True
+    return e.packed
 
 
 def gemm_split(a, packed, n, bias=None, residual=None, relu=False, out=None):
@@ -779,7 +896,7 @@ class ConvSplitFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad, relu):
         x = _nhwc(x)
         n, c, ks = weight.shape[0], weight.shape[1], weight.shape[2]
-        y = conv_split(x, split_pack_weight(weight), n, ks, stride, pad, bias, None, relu)
+        y = conv_split(x, split_pack_cached(weight), n, ks, stride, pad, bias, None, relu)
         ctx.cfg = (stride, pad, bool(relu), bias is not None)
         ctx.save_for_backward(x, weight, y if relu else x.new_empty(0))
         return y
@@ -800,8 +917,8 @@ class ConvSplitFn(torch.autograd.Function):
         want_dx = ctx.needs_input_grad[0]
         if want_dx and stride == 1 and n % 64 == 0 and c % 32 == 0:
             # dX[ci](p) = sum over taps, co of g[co](p + pad - tap) W[co, ci, tap]: a convolution of g with the taps flipped, roles of ci / co swapped
-            wt = weight.detach().flip(2, 3).permute(1, 0, 2, 3)                    # (C_in, C_out, kh, kw)
-            dx = conv_split(g, split_pack_weight(wt), c, ks, 1, ks - 1 - pad)
+            # (the weight is packed in that orientation where it lies: split_pack_cached 'dx')
+            dx = conv_split(g, split_pack_cached(weight, 'dx'), c, ks, 1, ks - 1 - pad)
             want_dx = False
         if want_dx or ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             gi, dw, db = torch.ops.aten.convolution_backward(g, x, weight, [n] if has_bias else None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
@@ -823,7 +940,7 @@ class LinearActFn(torch.autograd.Function):
             # round 5: the split-operand kernel (exact 3 x bf16 operand planes on the bf16 matrix cores), as at inference; a new output buffer -
             # the residual belongs to autograd
             r = None if residual is None else (residual if residual.is_contiguous() else residual.contiguous())
-            y = gemm_split(a, split_pack_weight(weight), n, bias, r, relu)
+            y = gemm_split(a, split_pack_cached(weight), n, bias, r, relu)
         elif residual is None:
             if relu and hasattr(torch, '_addmm_activation'):
                 y = torch._addmm_activation(bias, a, weight.t(), use_gelu=False)
@@ -848,7 +965,7 @@ class LinearActFn(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             da = None
         elif SPLIT_TRAIN and g.is_cuda and n % 64 == 0 and k % 32 == 0:
-            da = gemm_split(g, split_pack_weight(weight, transpose=True), k)          # dA (M, K) = g (M, N) . (W^T)^T: W^T packed as a (K, N) weight
+            da = gemm_split(g, split_pack_cached(weight, 'T'), k)          # dA (M, K) = g (M, N) . (W^T)^T: W^T packed as a (K, N) weight
         else:
             da = g @ weight
         dw = g.t() @ a if ctx.needs_input_grad[1] else None
