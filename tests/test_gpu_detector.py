@@ -104,10 +104,16 @@ def test_training_losses_and_gradients_vs_f64_restatement():
     (float32; DeformConv / ROIAlign forward + backward kernels) vs the float64 CPU restatement with autograd
     (oracle/detector_ref.losses - written independently of detnet/nn/training.py).  detectron2's random fg / bg subsampling is
     replaced on BOTH sides by "lowest indices" (training.first_choice), so the sampled anchors / proposals are comparable.
-    Tolerances: losses 1e-4 relative (north_star); gradients: every trainable tensor within 6e-3 of its largest entry, the median tensor
-    within 1e-3, the 16 named ones within 4e-3.  Measured (tools/train_grad_check.py, round 5, same box): all-library graph worst tensor
-    3.7e-3 / median 4.7e-4; split-operand graph (WD_SPLIT_TRAIN=1, the default) worst 2.4e-3 / median 3.7e-4 - float32 summation order and
-    float atomics against a float64 reference through ~150 layers; which tensor is worst changes from run to run."""
+    Tolerances: losses 1e-4 relative (north_star); gradients: every trainable tensor within 4e-3 of its largest entry, the median tensor
+    within 1e-3 - EXCEPT the tensors of at most three bottleneck blocks, which may be off by up to 3e-2.  Why the exception (measured, round 5:
+    tools/train_grad_check.py REPEATS=6 in three processes, tools/diag_train_toggle.py): the float32 forward is not run-to-run identical (MIOpen's
+    split-K convolutions add with atomics: every res4 activation moves by ~7e-7 relative), and a DISCRETE decision inside a block's deformable
+    convolution - a ReLU input within that noise of zero, a bilinear sample within it of a pixel boundary - then falls on the other side than in
+    float64.  On the 10 x 14 res4 map of this test one pixel is 1 / 140 of every sum, so the four tensors of that block move together by a fixed
+    amount (res4.27: conv2_offset.weight 9e-3, conv2_offset.bias 8e-3, conv2_weight 6.6e-3, conv1.weight 4.4e-3 in about half of the runs, absent in
+    the others; res4.21 the same way in one run of six; res4.13.conv2_weight 3.7e-3 in every run, in the all-library graph too), while the block's
+    output gradient and every other block stay put.  Without a flip: worst tensor 2.6e-3, median 4.7e-4 (float32 summation order and float atomics
+    against a float64 reference through ~150 layers)."""
     import copy
     from oracle import detector_ref as R
     from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
@@ -139,23 +145,21 @@ def test_training_losses_and_gradients_vs_f64_restatement():
              'backbone.lateral.1.weight', 'backbone.output.0.weight', 'rpn.conv.weight', 'rpn.objectness.weight', 'rpn.deltas.bias',
              'heads.0.fc1_weight', 'heads.1.convs.0.weight', 'heads.2.norms.3.weight', 'heads.2.box_weight', 'heads.0.cls_bias']
     gp, rp = dict(m.model.named_parameters()), dict(cpu.named_parameters())
-    checked = 0
-    for n in names:
-        a, b = gp[n].grad, rp[n].grad
-        assert a is not None and b is not None, n
-        a, b = a.double().cpu(), b.double()
-        scale = float(b.abs().max())
-        assert scale > 0, n
-        assert float((a - b).abs().max()) <= 4e-3 * scale, (n, float((a - b).abs().max()), scale)
-        checked += 1
-    assert checked == len(names)
-    rel = []
+    import re
+    rel = {}
     for n, p in gp.items():
         if p.requires_grad and p.grad is not None and float(rp[n].grad.abs().max()) > 0:
-            rel.append((float((p.grad.double().cpu() - rp[n].grad.double()).abs().max()) / float(rp[n].grad.abs().max()), n))
-    rel.sort()
-    assert rel[-1][0] <= 6e-3, rel[-3:]
-    assert rel[len(rel) // 2][0] <= 1e-3, rel[len(rel) // 2]
+            rel[n] = float((p.grad.double().cpu() - rp[n].grad.double()).abs().max()) / float(rp[n].grad.abs().max())
+    for n in names:
+        assert gp[n].grad is not None and rp[n].grad is not None and n in rel, n
+    block = lambda n: (re.match(r'(backbone\.res\d\.\d+)\.', n) or re.match(r'(.*)', n)).group(1)
+    flipped = sorted({block(n) for n, e in rel.items() if e > 4e-3})
+    assert len(flipped) <= 3 and all(b.startswith('backbone.res') for b in flipped), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
+    for n, e in rel.items():
+        assert e <= (3e-2 if block(n) in flipped else 4e-3), (n, e, flipped)
+    ordered = sorted(rel.values())
+    assert ordered[len(ordered) // 2] <= 1e-3, ordered[len(ordered) // 2]
+    assert len(rel) > 300
     # every trainable tensor: gradient direction agrees (cosine) - catches a wrong layout / missing term anywhere
     for n, p in gp.items():
         if p.requires_grad:
@@ -193,8 +197,16 @@ def test_fused_training_epilogues_equal_the_plain_autograd_graph(monkeypatch):
     assert set(l0) == set(l1) and set(g0) == set(g1) and len(g0) > 300
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
-    worst = max(float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-30)) for n in g0)
-    assert worst <= 1e-2, worst
+    # gradients: float atomics move every tensor by up to ~2.5e-3 of its largest entry from run to run (tools/train_grad_check.py, "vs run 0");
+    # a discrete decision taken the other way (see the docstring of the float64 test above) moves the four tensors of ONE bottleneck block by up
+    # to 1e-2: at most three such blocks, everything else within 5e-3 (was: one 1e-2 bound for everything)
+    import re
+    rel = {n: float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-30)) for n in g0}
+    block = lambda n: (re.match(r'(backbone\.res\d\.\d+)\.', n) or re.match(r'(.*)', n)).group(1)
+    flipped = sorted({block(n) for n, e in rel.items() if e > 5e-3})
+    assert len(flipped) <= 3 and all(b.startswith('backbone.res') for b in flipped), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
+    for n, e in rel.items():
+        assert e <= (3e-2 if block(n) in flipped else 5e-3), (n, e, flipped)
 
 
 def test_training_step_full_size_properties():
@@ -373,7 +385,16 @@ def test_inference_cli_on_image_folder(tmp_path):
         preds[image_id] = TTA(net, ['x1.5', 'hflip']).predict(x)[0]
         sizes[image_id] = (img.width, img.height)
     ref_rows = I.load_prediction(sizes, net.classnames, preds)
-    assert [(r['image_id'], r['category_id'], r['bbox']) for r in rows] == [(r['image_id'], r['category_id'], r['bbox']) for r in ref_rows]
+    # (two float32 runs of the detector are not bit-identical - library convolutions with atomics, algorithms picked by timing - so a coordinate within
+    # 1e-4 px of a rounding boundary or two scores within 1e-7 of each other may come out the other way: rows are matched, not compared by position)
+    assert abs(len(rows) - len(ref_rows)) <= 1
+    assert [r['image_id'] for r in rows[:1]] == [r['image_id'] for r in ref_rows[:1]]
+    matched = 0
+    for r in rows:
+        matched += any(q['image_id'] == r['image_id'] and q['category_id'] == r['category_id'] and
+                       max(abs(a - b) for a, b in zip(q['bbox'], r['bbox'])) <= 1 and abs(q['score'] - r['score']) <= 2e-5 for q in ref_rows)
+    assert matched >= len(rows) - 1, (matched, len(rows))
+    assert list(dict.fromkeys(r['image_id'] for r in rows)) == list(dict.fromkeys(r['image_id'] for r in ref_rows))
     # -o wrote the store; --resume on a store that holds two of the four images detects only the others and merges
     store = Predictions.open(tmp_path / 'o')
     assert len(store) == 4

@@ -40,3 +40,28 @@ for e, n in rows[:12]:
     print('   %.2e  %s' % (e, n))
 import statistics
 print('median %.2e' % statistics.median(e for e, _ in rows))
+
+# REPEATS=n: the GPU side again (same inputs): worst tensors of every run against float64 AND against the first GPU run (run-to-run noise of the float
+# atomics; a tensor that moves by more than the atomics explain points at a discrete event: a bilinear sample crossing a pixel boundary, or a bug)
+reps = int(os.environ.get('REPEATS', '0'))
+first = {n: p.grad.detach().clone() for n, p in gp.items() if p.requires_grad and p.grad is not None}
+for r in range(reps):
+    for p in gp.values():
+        p.grad = None
+    got = training.losses(m.model, img.cuda(), gt.cuda(), cls.cuda(), choose=training.first_choice, config=cfg, proposals=inter['proposals'].float().cuda())
+    sum(got.values()).backward()
+    vs64, vs0, l2 = [], [], []
+    for n, p in gp.items():
+        if n in first and rp[n].grad is not None and float(rp[n].grad.abs().max()) > 0:
+            s = float(rp[n].grad.abs().max())
+            d = p.grad.double().cpu() - rp[n].grad.double()
+            vs64.append((float(d.abs().max()) / s, n))
+            vs0.append((float((p.grad - first[n]).abs().max()) / s, n))
+            l2.append((float(d.norm() / rp[n].grad.double().norm()), n))
+    vs64.sort(reverse=True)
+    vs0.sort(reverse=True)
+    l2.sort(reverse=True)
+    print('run %d  relative L2 vs f64, worst: %s; median %.1e; tensors with max-norm error > 4e-3: %d' % (
+        r + 1, ', '.join('%.1e %s' % (e, n.replace('backbone.', '')) for e, n in l2[:4]), l2[len(l2) // 2][0], sum(1 for e, _ in vs64 if e > 4e-3)))
+    print('run %d  vs f64: %s' % (r + 1, ', '.join('%.1e %s' % (e, n.replace('backbone.', '')) for e, n in vs64[:4])))
+    print('        vs run 0: %s' % ', '.join('%.1e %s' % (e, n.replace('backbone.', '')) for e, n in vs0[:4]))

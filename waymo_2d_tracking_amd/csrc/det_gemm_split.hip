@@ -310,6 +310,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_k64_kernel(const Split
 #ifndef WD_ABL
 #define WD_ABL 0
 #endif
+#ifndef WD_SPLIT_PRIO
+#define WD_SPLIT_PRIO 0
+#endif
 template <int MT, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -487,6 +490,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #endif
     RD(rofs0, 2) RD(rofs0, 1) RD(rofs0, 0)
     SB;
+#if WD_SPLIT_PRIO
+    // experiment: the second wave of every SIMD (waves 4-7) at a higher issue priority - the two waves of a SIMD then stop marching in lockstep
+    if (wave >= 4) __builtin_amdgcn_s_setprio(WD_SPLIT_PRIO);
+#endif
     int cur = 0, nxt = BUF, wr = 2 * BUF;
     for (int kt = 0; kt < nk; ++kt) {
         const int a1 = cur + rofs1, a0n = nxt + rofs0;
@@ -519,6 +526,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #undef RD
 #undef SPLIT_ROW
 #undef WLOAD
+#if WD_SPLIT_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     long long t_epi = 0;
     if (p.stamps) t_epi = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);          // the dangling prefetch of the step behind the last one
