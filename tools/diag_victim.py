@@ -17,6 +17,7 @@ xg = torch.randn(1, 256, 64, 96, device='cuda').contiguous(memory_format=torch.c
 wg = ops.deform_pack_weight(torch.randn(256, 8, 3, 3, device='cuda') / 8.5, 32)
 ma = torch.randn(6144, 256, device='cuda'); mb = torch.randn(256, 256, device='cuda')
 sink = torch.zeros(4, dtype=torch.int32, device='cuda')
+cflags = torch.zeros(8, dtype=torch.int32, device='cuda')
 
 
 def aggress():
@@ -28,6 +29,18 @@ def aggress():
         ops.deform_conv3x3(xg, None, wg, 32, 1, 1, None, None, True)
     elif AGG == 'mm':
         torch.mm(ma, mb.t())
+    elif AGG.startswith('canary'):                       # canaryN: N busy workgroups (VALU / f32 MFMA / LDS reads), 36 KB of LDS, few registers
+        import ctypes as C
+        from waymo_2d_tracking_amd import _lib
+        _lib.check(_lib.lib().wd_debug_canary(C.c_int(int(AGG[6:])), C.c_int(int(os.environ.get('CANARY_LDS', '36864'))), C.c_int(int(os.environ.get('CANARY_SPINS', '30'))),
+                                              C.c_void_p(cflags.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'canary')
+    elif AGG.startswith('dirty'):                        # dirtyN: N workgroups that fill DIRTY_LDS bytes of LDS with NaN patterns and leave
+        import ctypes as C
+        from waymo_2d_tracking_amd import _lib
+        nb = int(os.environ.get('DIRTY_LDS', '36864'))
+        sink[1] = nb
+        _lib.check(_lib.lib().wd_debug_occupy(C.c_int(int(AGG[5:])), C.c_int(nb), C.c_longlong(-300), C.c_void_p(sink.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'occupy')
     elif AGG.startswith('occupy'):                       # occupyN: N idle workgroups holding 112 KiB of LDS each for ~30 us
         import ctypes as C
         from waymo_2d_tracking_amd import _lib

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_k64_kernel(const Split
     // LDS writes sit in the read-free slots of sub-steps 2 and 3, each row block's global load for the K step after that right behind its split
     // (a full K step of MFMAs ahead of its use).
     bf16x8 af[MT][3];
+using F4_ = __attribute__((ext_vector_type(4))) float;
 #define SB __builtin_amdgcn_sched_barrier(0)
 #define MF(pa, pb, slot)                                                                                      \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
@@ -455,7 +456,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #define SB __builtin_amdgcn_sched_barrier(0)
     // compile-time ablations for tools/split_ablation.sh (timing only, results wrong): WD_ABL bit 0 no A global loads, 1 no split / LDS
     // writes, 2 no W loads, 3 no barrier, 4 no MFMAs, 5 no fragment reads, 6 W loads always from K step 0 (cache hits), 7 A loads always from K step 0
-#if WD_ABL & 16
+#if WD_ABL & 256      /* diagnostics: the MFMA's issue time as s_nop (no matrix-pipe work) */
+#define MF(pa, pb, slot)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" :: "v"(af[i][pa]), "v"(wf[slot][pb])); }
+#elif WD_ABL & 512    /* diagnostics: an f32 MFMA (32x32x2, 64 cycles) in place of every bf16 MFMA */
+#define MF(pa, pb, slot)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                          \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(F4_, af[i][pa])[0], __builtin_bit_cast(F4_, wf[slot][pb])[0], acc[i], 0, 0, 0);
+#elif WD_ABL & 1024   /* diagnostics: the bf16 MFMA on constant-zero operands (same pipe occupancy, no data toggling) */
+#define MF(pa, pb, slot)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                        \
+        bf16x8 z_ = {}; asm volatile("" : "+v"(z_) : "v"(af[i][pa]), "v"(wf[slot][pb]));                      \
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z_, z_, acc[i], 0, 0, 0); }
+#elif WD_ABL & 16
 #define MF(pa, pb, slot)                                                                                      \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(af[i][pa]), "v"(wf[slot][pb]));
 #else
@@ -1099,11 +1112,22 @@ __global__ __launch_bounds__(256, 2) void canary_kernel(int lds_bytes, int spins
 #pragma unroll 8
         for (int j = 0; j < 64; ++j) x = __builtin_fmaf(x, 1.0f, 1.0f);
         if (x != (float)((tid & 63) + 64)) ++bad_v;
-        // MFMA chain: A = ones (16 x 4), B = ones (4 x 16): every product tile is 4; 8 accumulations -> 32
+        // f32 MFMA chain with DISTINCT small-integer operands per lane and per step (all-ones operands cannot show an operand mix-up):
+        // A_j[i][k] = i + 2 k + j, B_j[k][n] = n + 3 k + 1 + j (lane l holds A[l % 16][l / 16] and B[l / 16][l % 16]);
+        // D[i][n] = sum_j sum_k A_j[i][k] B_j[k][n], exact in float32; lane l holds D[4 (l / 16) + r][l % 16], r = 0..3
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int ln = tid & 63, li = ln & 15, lk = ln >> 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, 1.0f, acc, 0, 0, 0);
-        if (acc[0] != 32.f || acc[1] != 32.f || acc[2] != 32.f || acc[3] != 32.f) ++bad_m;
+        for (int j = 0; j < 8; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(li + 2 * lk + j + (s & 3)), (float)(li + 3 * lk + 1 + j), acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * lk + r, nn = li;
+            int want = 0;
+            for (int j = 0; j < 8; ++j)
+                for (int k = 0; k < 4; ++k) want += (i + 2 * k + j + (s & 3)) * (nn + 3 * k + 1 + j);
+            if (acc[r] != (float)want) ++bad_m;
+        }
         for (int i = tid; i < n; i += 256)
             if (l[i] != 0x9E3779B9u * (unsigned)(i + 1) + blockIdx.x) ++bad_l;
 #pragma unroll
@@ -1133,6 +1157,12 @@ extern "C" int wd_debug_canary(int workgroups, int lds_bytes, int spins, unsigne
 namespace {
 __global__ __launch_bounds__(512) void occupy_kernel(long long ticks, unsigned* __restrict__ sink) {
     extern __shared__ unsigned char osm[];
+    if (ticks < 0) {                               // "dirty" occupant: leaves its whole LDS allocation full of NaN bit patterns
+        ticks = -ticks;
+        unsigned* w = reinterpret_cast<unsigned*>(osm);
+        for (int i = threadIdx.x; i < (int)(sink[1] / 4); i += 512) w[i] = 0x7FC01234u;
+        __syncthreads();
+    }
     const long long t0 = __builtin_amdgcn_s_memtime();
     unsigned acc = 0;
     while (__builtin_amdgcn_s_memtime() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); acc += osm[threadIdx.x]; }
