@@ -572,6 +572,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 // a whole K step ahead), so no second wave is needed to hide latency.  A rows are staged as float4 per thread (256 threads: 8 x 16 bytes per
 // 32-float row, 5 row blocks), three ds_write_b64 per row block.
 constexpr int W4_THREADS = 256;
+// row blocks per epilogue pass of the four-wave kernel: 3 = 96 KB of LDS; 1 = 32 KB, so that the ring (18 KB per row block) sizes the workgroup and two
+// workgroups of MT <= 3 share a CU (their prologues / epilogues then run under each other's main loop: the short-K shapes)
+#ifndef WD_W4_PASS
+#define WD_W4_PASS 3
+#endif
 
 template <int MT, bool DUAL>
 __device__ __forceinline__ void split_epilogue_w4(const SplitArgs& p, unsigned char* smem, f32x16 (&acc)[2][MT], const f32x16 (&accs)[2][DUAL ? MT : 1], int m0, int n0,
@@ -583,8 +588,8 @@ __device__ __forceinline__ void split_epilogue_w4(const SplitArgs& p, unsigned c
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && c4 < ncols) bv = *reinterpret_cast<const float4*>(p.bias + n0 + c4);
 #pragma unroll
-    for (int i0 = 0; i0 < MT; i0 += 3) {
-        constexpr int PASS = 3;
+    for (int i0 = 0; i0 < MT; i0 += WD_W4_PASS) {
+        constexpr int PASS = WD_W4_PASS;
         if (i0 > 0) __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = i0; i < i0 + PASS && i < MT; ++i)
@@ -929,7 +934,9 @@ int launch(const SplitArgs& a, hipStream_t stream) {
     constexpr size_t lds_epi = 32u * (MT < 3 ? MT : 3) * BN * 4u;
     constexpr size_t lds_k64 = 2u * 3u * 32u * MT * 128u, lds_ring = 3u * 3u * 32u * MT * 64u;
     const size_t lds_main = kc == 1 ? lds_k64 : lds_ring;
-    const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    constexpr size_t lds_epi_w4 = 32u * (MT < WD_W4_PASS ? MT : WD_W4_PASS) * BN * 4u;
+    const size_t lds_e = kc >= 2 ? lds_epi_w4 : lds_epi;
+    const size_t lds = lds_main > lds_e ? lds_main : lds_e;
     const void* fn = reinterpret_cast<const void*>(gemm_split_kernel<MT, MODE>);
     if constexpr (MT <= 5) {
         if (kc == 1) fn = reinterpret_cast<const void*>(gemm_split_k64_kernel<MT, MODE>);
