@@ -314,6 +314,9 @@ using F4_ = __attribute__((ext_vector_type(4))) float;
 #ifndef WD_SPLIT_PRIO
 #define WD_SPLIT_PRIO 0
 #endif
+#ifndef WD_SPLIT_RESPF
+#define WD_SPLIT_RESPF 0        // experiment, off: K steps between a residual prefetch into L2 and the epilogue (measured with 3 and 6: 2 - 4 % SLOWER)
+#endif
 template <int MT, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -507,9 +510,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     // experiment: the second wave of every SIMD (waves 4-7) at a higher issue priority - the two waves of a SIMD then stop marching in lockstep
     if (wave >= 4) __builtin_amdgcn_s_setprio(WD_SPLIT_PRIO);
 #endif
+    // EXPERIMENT (-DWD_SPLIT_RESPF=3|6, off by default): residual tile -> L2 a few K steps before the epilogue asks for it, one dword per 128-byte
+    // line, results never read (inline asm: older than any load the compiler tracks, so its vmcnt waits only get more conservative; the destination
+    // registers stay allocated until the epilogue is over).  The idea: every workgroup starts its epilogue with a cold HBM round trip for 1 KiB x BM
+    // of residual, all at the same moment (8 k cycles of epilogue without a residual, 24 k with one).  Measured (three alternating rounds, res4 / res3 /
+    // res2 with the full epilogue, profiles/r05_split_respf.txt): 128 -> 132, 144 -> 149, 192 -> 197 us; e2e 37.8 -> 37.5 frames/s on that box: the
+    // epilogue is bound by the HBM burst itself, not by its latency, and the early requests only compete with the A / W stream.
+    constexpr int RESPF_N = (WD_SPLIT_RESPF && MT <= 5) ? (BM * 8 + NTHREADS - 1) / NTHREADS : 0;
+    float respf[RESPF_N > 0 ? RESPF_N : 1];
+    const int respf_at = (nk > WD_SPLIT_RESPF) ? nk - WD_SPLIT_RESPF : 0;
+    const bool respf_on = RESPF_N > 0 && p.residual != nullptr && p.splitk == 1;
     int cur = 0, nxt = BUF, wr = 2 * BUF;
     for (int kt = 0; kt < nk; ++kt) {
         const int a1 = cur + rofs1, a0n = nxt + rofs0;
+        if constexpr (RESPF_N > 0) {
+            if (respf_on && kt == respf_at) {
+                const int ncols = p.N - n0 < BN ? p.N - n0 : BN;
+#pragma unroll
+                for (int j = 0; j < RESPF_N; ++j) {
+                    const int L = tid + NTHREADS * j, row = L >> 3, seg = L & 7;
+                    const bool ok = row < BM && m0 + row < p.M && seg * 32 < ncols;
+                    const float* q = p.residual + (ok ? (size_t)(m0 + row) * p.ldc + n0 + seg * 32 : (size_t)0);
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(respf[j]) : "v"(q) : "memory");
+                }
+            }
+        }
         // sub-step 0 (fragments in registers); its slots request sub-step 1's fragments of the same buffer.  The W fragments of a sub-step are
         // reloaded right behind its last MFMA, a whole K step ahead of their next use (measured: spreading the eight waves' reloads over
         // different slots of the other sub-step - no burst in the vector-memory path, but 2-5 slots of lead - costs 9 % of the main loop)
@@ -554,6 +579,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
         split_epilogue<MT>(q, smem, acc, m0, n0, wave, lane);
     } else {
         split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane);
+    }
+    if constexpr (RESPF_N > 0) {
+#pragma unroll
+        for (int j = 0; j < RESPF_N; ++j) asm volatile("" :: "v"(respf[j]));       // the prefetch targets: allocated until here
     }
     if (p.stamps && tid == 0) {
         long long* o = p.stamps + 8 * (long)blockIdx.x;
