@@ -53,3 +53,31 @@ def test_product_never_imports_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b|wt_oracle\.h|libwt_oracle', txt, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_split_pack_descriptor_layout_matches_the_header():
+    """ops._pack_desc_dtype (the host-side array handed to wd_gemm_split_pack_batch) == struct WdSplitPackDesc of include/waymodet.h: same field order,
+    offsets and size (the header is parsed, not restated)."""
+    import ctypes as C
+    import re
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    text = open(os.path.join(ROOT, 'include', 'waymodet.h')).read()
+    body = re.search(r'typedef struct WdSplitPackDesc \{(.*?)\} WdSplitPackDesc;', text, re.S).group(1)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype = C.c_void_p if '*' in decl else (C.c_long if decl.startswith('long') else C.c_int)
+        names = decl.replace('*', ' ').split(None, 2 if decl.startswith('const') else 1)[-1]
+        for name in names.split(','):
+            fields.append((name.strip(), ctype))
+
+    class Desc(C.Structure):
+        _fields_ = fields
+
+    dt = ops._pack_desc_dtype()
+    assert dt.itemsize == C.sizeof(Desc) == 80
+    assert [n for n, _ in fields] == list(dt.names) == list(ops._PACK_DESC_FIELDS)
+    for name, _ in fields:
+        assert dt.fields[name][1] == getattr(Desc, name).offset, name
