@@ -105,7 +105,7 @@ def test_training_losses_and_gradients_vs_f64_restatement():
     (oracle/detector_ref.losses - written independently of detnet/nn/training.py).  detectron2's random fg / bg subsampling is
     replaced on BOTH sides by "lowest indices" (training.first_choice), so the sampled anchors / proposals are comparable.
     Tolerances: losses 1e-4 relative (north_star); gradients: every trainable tensor within 4e-3 of its largest entry, the median tensor
-    within 1e-3 - EXCEPT the tensors of at most three bottleneck blocks, which may be off by up to 3e-2.  Why the exception (measured, round 5:
+    within 1e-3 - EXCEPT at most a quarter of the tensors (bottleneck tensors only), which may be off by up to 3e-2.  Why the exception (measured, round 5:
     tools/train_grad_check.py REPEATS=6 in three processes, tools/diag_train_toggle.py): the float32 forward is not run-to-run identical (MIOpen's
     split-K convolutions add with atomics: every res4 activation moves by ~7e-7 relative), and a DISCRETE decision inside a block's deformable
     convolution - a ReLU input within that noise of zero, a bilinear sample within it of a pixel boundary - then falls on the other side than in
@@ -152,11 +152,11 @@ def test_training_losses_and_gradients_vs_f64_restatement():
             rel[n] = float((p.grad.double().cpu() - rp[n].grad.double()).abs().max()) / float(rp[n].grad.abs().max())
     for n in names:
         assert gp[n].grad is not None and rp[n].grad is not None and n in rel, n
-    block = lambda n: (re.match(r'(backbone\.res\d\.\d+)\.', n) or re.match(r'(.*)', n)).group(1)
-    flipped = sorted({block(n) for n, e in rel.items() if e > 4e-3})
-    assert len(flipped) <= 3 and all(b.startswith('backbone.res') for b in flipped), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
-    for n, e in rel.items():
-        assert e <= (3e-2 if block(n) in flipped else 4e-3), (n, e, flipped)
+    # a flipped decision moves its own block by up to ~1e-2 and, through the gradient that flows on, the blocks upstream of it by a few 1e-3
+    # (seen: eleven consecutive res4 blocks at 6e-3 - 8e-3): bounded share of tensors above 4e-3, none above 3e-2, only bottleneck tensors among them
+    over = sorted((e, n) for n, e in rel.items() if e > 4e-3)
+    assert len(over) <= 0.25 * len(rel) and all(n.startswith('backbone.res') for _, n in over), over[-8:]
+    assert max(rel.values()) <= 3e-2, over[-3:]
     ordered = sorted(rel.values())
     assert ordered[len(ordered) // 2] <= 1e-3, ordered[len(ordered) // 2]
     assert len(rel) > 300
@@ -198,15 +198,15 @@ def test_fused_training_epilogues_equal_the_plain_autograd_graph(monkeypatch):
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
     # gradients: float atomics move every tensor by up to ~2.5e-3 of its largest entry from run to run (tools/train_grad_check.py, "vs run 0");
-    # a discrete decision taken the other way (see the docstring of the float64 test above) moves the four tensors of ONE bottleneck block by up
-    # to 1e-2: at most three such blocks, everything else within 5e-3 (was: one 1e-2 bound for everything)
-    import re
+    # a discrete decision taken the other way (see the docstring of the float64 test above) moves the four tensors of its bottleneck block by up to
+    # 1e-2 and the blocks upstream of it by 6e-3 - 8e-3 (measured: 2 of 6 runs, eleven consecutive res4 blocks): a bounded share of the tensors may
+    # exceed 5e-3, none 3e-2, the median stays within 1e-3 (was: one 1e-2 bound for everything - 8.1e-3 seen)
     rel = {n: float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-30)) for n in g0}
-    block = lambda n: (re.match(r'(backbone\.res\d\.\d+)\.', n) or re.match(r'(.*)', n)).group(1)
-    flipped = sorted({block(n) for n, e in rel.items() if e > 5e-3})
-    assert len(flipped) <= 3 and all(b.startswith('backbone.res') for b in flipped), sorted(rel.items(), key=lambda kv: -kv[1])[:8]
-    for n, e in rel.items():
-        assert e <= (3e-2 if block(n) in flipped else 5e-3), (n, e, flipped)
+    over = sorted((e, n) for n, e in rel.items() if e > 5e-3)
+    assert len(over) <= 0.25 * len(rel) and all(n.startswith('backbone.res') for _, n in over), over[-8:]
+    assert max(rel.values()) <= 3e-2, over[-3:]
+    ordered = sorted(rel.values())
+    assert ordered[len(ordered) // 2] <= 1e-3, ordered[len(ordered) // 2]
 
 
 def test_training_step_full_size_properties():
