@@ -923,7 +923,9 @@ Plan pick_plan(long M, int N, int K, bool allow_split) {
     // (deform_conv3x3_kernel<64, true>) and of the grouped 3x3 kernel on ANOTHER stream return a few hundred slightly wrong outputs each (196 of 200
     // launches at MT = 2, 38 of 200 at MT = 3, none at MT = 4 / 5; none next to idle workgroups holding the same LDS; a canary workgroup - LDS
     // pattern, 200 live registers, VALU and f32-MFMA chains - next to the same launches stays clean, the split kernel's own results are never
-    // affected, reserving 112 KiB of LDS does not help).  The mechanism is not understood; the two-pipeline test
+    // affected, reserving 112 KiB of LDS does not help).  Narrowed down (profiles/r05_costream_interference.txt): it takes co-residency on a CU AND
+    // bf16 MFMAs on real operand data in the small-tile workgroups (zero operands, s_nop in place of the MFMAs, dirty LDS, busy canaries: all clean) -
+    // no software state is shared; with >= 4 row blocks no SIMD has room for those 230 / 256-VGPR kernels next to two split waves.  The two-pipeline test
     // (tests/test_gpu_e2e.py::test_two_pipelines_in_flight_on_different_streams_equal_serial_runs) is bit-identical with >= 4 row blocks.
     const int mt_min = (forced_mt == 2 || forced_mt == 3) ? forced_mt : 4;
     for (int mt = mt_max; mt >= mt_min; --mt) {
