@@ -46,7 +46,9 @@ SPLIT_GEMM = os.environ.get('WD_SPLIT_GEMM', '1') != '0'
 
 _SKIP = set(os.environ.get('WD_SPLIT_SKIP', '').split(','))      # experiments: 'cin-cout-stride-hasresidual' 1x1 shapes kept on the library
 _INPLACE = os.environ.get('WD_SPLIT_INPLACE', '1') != '0'      # experiments: 0 = block outputs in fresh buffers instead of the residual's
-SPLIT_PARTS = set(os.environ.get('WD_SPLIT_PARTS', 'conv1x1,conv3x3,head,fc').split(','))     # experiments: which layer families use the kernel
+SPLIT_PARTS = set(os.environ.get('WD_SPLIT_PARTS', 'conv1x1,conv3x3,head,fc,offset').split(','))     # experiments: which layer families use the kernel
+# the N-thin GEMM of the 18-channel offset convolution goes to the split kernel from this many rows (res3 at full size; below, the library is as fast)
+OFFSET_SPLIT_MIN_ROWS = int(os.environ.get('WD_OFFSET_SPLIT_MIN_ROWS', '30000'))
 
 
 def _split_ok(cin, cout, part='conv1x1'):
@@ -219,7 +221,13 @@ class Bottleneck(nn.Module):
         if getattr(self, '_off_w2', None) is None or self._off_w2.device != w.device or self._off_v != w._version:
             self._off_w2 = ops.tap_gemm_weight(w)
             self._off_v = w._version
-        return ops.conv3x3_few(x, self._off_w2, self.conv2_offset.bias, 18, 1, deform_table)
+        split = None
+        if x.shape[0] * x.shape[2] * x.shape[3] >= OFFSET_SPLIT_MIN_ROWS and x.is_cuda and _split_ok(w.shape[1], 32, 'offset'):
+            if getattr(self, '_off_split', None) is None or self._off_split_key != (w.device, w._version):
+                w32 = ops.tap_gemm_weight(w, align=32)              # 162 -> 192 rows (zero rows): N % 32 == 0 for the split kernel
+                self._off_split, self._off_split_key = (ops.split_pack_weight(w32), w32.shape[0]), (w.device, w._version)
+            split = self._off_split
+        return ops.conv3x3_few(x, self._off_w2, self.conv2_offset.bias, 18, 1, deform_table, split=split)
 
     def forward(self, x):
         sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)

@@ -287,7 +287,7 @@ def tap_gemm_weight(weight, align=16):
     return w2
 
 
-def conv3x3_few(x, w2, bias, n_out, stride=1, deform_table=False):
+def conv3x3_few(x, w2, bias, n_out, stride=1, deform_table=False, split=None):
     """3x3 conv, pad 1, with few output channels (the 18-channel deformable-offset conv) = one library GEMM over the
     input pixels (N = 9*n_out columns, full MFMA tiles) + the wd_tap_shift_add_f32 gather.  x (N,C,H,W) channels_last;
     returns (N,n_out,Ho,Wo) channels_last.  deform_table=True (n_out 18, stride 1): the gather launch also emits the sampling
@@ -295,17 +295,25 @@ def conv3x3_few(x, w2, bias, n_out, stride=1, deform_table=False):
     x = _nhwc(x)
     n, c, h, w = x.shape
     a = x.permute(0, 2, 3, 1).reshape(n * h * w, c)
-    partial = torch.mm(a, w2.t())
+    if split is not None:
+        # (packed planes of the same weight with ld rounded up to 32, ld): the N-thin GEMM on the split-operand kernel - pays from ~30 000 rows
+        # (res3 at 1920 x 1280: 58 vs 78 us; res4's 9600 rows: 40 vs 39 us, left on the library; profiles/r05_offset_gemm_split.txt)
+        packed, ld = split
+        partial = gemm_split(a, packed, ld)
+        ld_partial = ld
+    else:
+        partial = torch.mm(a, w2.t())
+        ld_partial = w2.shape[0]
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     out = torch.empty((n, n_out, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if deform_table:
         assert n_out == 18 and stride == 1
         lib = _lib.lib()
         table = torch.empty(int(lib.wd_deform_table_bytes(C.c_int(n), C.c_int(h), C.c_int(w))), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.wd_deform_offsets_table_f32(_p(partial), C.c_int(w2.shape[0]), _p(bias), C.c_int(n), C.c_int(h), C.c_int(w),
+        _lib.check(lib.wd_deform_offsets_table_f32(_p(partial), C.c_int(ld_partial), _p(bias), C.c_int(n), C.c_int(h), C.c_int(w),
                                                    _p(out), _p(table), _stream()), 'wd_deform_offsets_table_f32')
         return out, table
-    _lib.check(_lib.lib().wd_tap_shift_add_f32(_p(partial), C.c_int(w2.shape[0]), C.c_int(n_out), _p(bias), C.c_int(n), C.c_int(h),
+    _lib.check(_lib.lib().wd_tap_shift_add_f32(_p(partial), C.c_int(ld_partial), C.c_int(n_out), _p(bias), C.c_int(n), C.c_int(h),
                                                C.c_int(w), C.c_int(stride), _p(out), _stream()), 'wd_tap_shift_add_f32')
     return out
 
