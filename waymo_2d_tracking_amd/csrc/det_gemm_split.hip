@@ -314,6 +314,9 @@ using F4_ = __attribute__((ext_vector_type(4))) float;
 #ifndef WD_SPLIT_PRIO
 #define WD_SPLIT_PRIO 0
 #endif
+#ifndef WD_SPLIT_CURSOR
+#define WD_SPLIT_CURSOR 1       // conv mode: (tap, channel block) of the fetched K step kept as a cursor (0: divided out of kt per row block)
+#endif
 #ifndef WD_SPLIT_RESPF
 #define WD_SPLIT_RESPF 0        // experiment, off: K steps between a residual prefetch into L2 and the epilogue (measured with 3 and 6: 2 - 4 % SLOWER)
 #endif
@@ -391,6 +394,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
         }
     };
     auto a_load_row = [&](int kt, int i) { araw[i] = a_fetch(kt, i); };
+    // MODE 1, main loop: the (tap, channel block) of the K step being fetched is a CURSOR advanced once per iteration - a_fetch divides it out of kt for
+    // every row block (217 scalar instructions per wave and K step in the box-head convolution, as many as its vector instructions: profiles/
+    // r05_split_pmc_conv.txt)
+    int f_idx = 0, f_tap = 0, f_cb = 0;
+    unsigned f_delta = 0;
+    auto f_place = [&]() {
+        const int dy = p.ksize == 3 ? (f_tap * 11) >> 5 : 0, dx = f_tap - dy * p.ksize;      // tap / 3 for tap < 9
+        f_delta = (unsigned)((dy * p.W + dx) * p.C + f_cb * 32);
+    };
+    auto f_set = [&](int kt) {
+        f_idx = kt < nk ? kt : nk - 1;
+        const int ks = k0 + f_idx;
+        f_tap = ks / kc; f_cb = ks - f_tap * kc;
+        f_place();
+    };
+    auto f_advance = [&](int kt) {                  // -> K step min(kt, nk - 1), one ahead of the current one at most
+        if (kt < nk && kt > f_idx) {
+            ++f_idx;
+            if (++f_cb == kc) { f_cb = 0; ++f_tap; }
+            f_place();
+        }
+    };
+    auto a_fetch_cur = [&](int i) -> float2 {
+        const bool ok = ((vmask[i] >> f_tap) & 1u) != 0;
+        const unsigned off = ok ? aoff[i] + f_delta : 2u * sk2;
+        const float2 v = *reinterpret_cast<const float2*>(p.a + (size_t)off);
+        return ok ? v : make_float2(0.f, 0.f);
+    };
     const int wofs = srow * 64 + ((((sk2 >> 2) ^ ((srow >> 2) & 3))) << 4) + ((sk2 & 3) << 2);
     auto a_store_val = [&](int bufoff, int i, float2 v) {     // split a row block's float2 and write its three planes (one bf16 pair each)
         unsigned char* base = smem + bufoff + wofs + i * 2048;
@@ -494,7 +525,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #elif WD_SPLIT_ADEEP
     // A rows two K steps ahead (a second register set): araw = step kt + 2 (split now), aahead = step kt + 3, reload with step kt + 4
 #define SPLIT_ROW(i_)                                                                                         \
-    if ((i_) < MT) { a_store_row(wr, (i_)); araw[(i_)] = aahead[(i_)]; aahead[(i_)] = a_fetch(kt + 4, (i_)); }
+    if ((i_) < MT) { a_store_row(wr, (i_)); araw[(i_)] = aahead[(i_)]; aahead[(i_)] = (MODE == 1 && WD_SPLIT_CURSOR && !(WD_ABL & 128)) ? a_fetch_cur((i_)) : a_fetch(kt + 4, (i_)); }
 #else
 #define SPLIT_ROW(i_)                                                                                         \
     if ((i_) < MT) { a_store_row(wr, (i_)); a_load_row(kt + 3, (i_)); }
@@ -521,6 +552,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     const int respf_at = (nk > WD_SPLIT_RESPF) ? nk - WD_SPLIT_RESPF : 0;
     const bool respf_on = RESPF_N > 0 && p.residual != nullptr && p.splitk == 1;
     int cur = 0, nxt = BUF, wr = 2 * BUF;
+    if (MODE == 1) f_set(4);
     for (int kt = 0; kt < nk; ++kt) {
         const int a1 = cur + rofs1, a0n = nxt + rofs0;
         if constexpr (RESPF_N > 0) {
@@ -558,6 +590,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #endif
         SB;
         const int t = cur; cur = nxt; nxt = wr; wr = t;
+        if (MODE == 1) f_advance(kt + 5);         // the next iteration fetches K step kt + 5
     }
 #undef SB
 #undef MF
