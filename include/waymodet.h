@@ -61,13 +61,18 @@ int wd_gemm_lt_f32(const float* a, const float* w, const float* bias, const floa
 int wd_gemm_lt_plan_info(int m, int n, int k, int relu, int has_bias, int has_residual, float* best_us, int* candidates);
 /* fp32-equivalent GEMM on the bf16 matrix cores (csrc/det_gemm_split.hip): every f32 operand is carried EXACTLY as three bfloat16
  * planes (hi + mid + lo by successive round-to-nearest subtraction), the six cross terms with i + j <= 2 run on
- * v_mfma_f32_32x32x16_bf16 with f32 accumulation; error against float64 not above the exact-f32 kernels' (tests/test_gpu_gemm_split.py).
+ * v_mfma_f32_32x32x16_bf16 with f32 accumulation.  Accuracy: the dropped cross terms are bounded by ~2^-25 |a.b| per product (the order of
+ * one f32 product rounding); the MEASURED error against float64 is not above the exact-f32 kernels' on the tested distributions
+ * (tests/test_gpu_gemm_split.py, incl. operands chosen to maximise the small planes).  Semantics that differ from an f32 GEMM: an operand
+ * that is +-inf or NaN makes its output elements NaN (f32: +-inf where no NaN is involved), and operands below 2^-110 in magnitude lose
+ * their lowest plane (bfloat16 underflow).  Finite post-ReLU activations and weights - the detector's operands - are unaffected.
  * Replaces the 1x1 convolutions of detectron2's BottleneckBlock (conv1 / conv3 / shortcut, job.log:534-546), the FPN lateral convs
  * (job.log:1093-1108) and - wd_conv_split_f32 - the dense 3x3 convolutions of FPN output / RPN / box heads (job.log:1109-1160).
  *   wd_gemm_split_pack_weight : w (N, K) f32 row-major -> `packed` (wd_gemm_split_packed_bytes(N, K) bytes, MFMA fragment order); once per weight.
  *                               For a 3x3 convolution pass w as (N, 9 * C) with k = (kh * 3 + kw) * C + c.
  *   wd_gemm_split_f32         : out (M, N) = relu?(a (M, K; row stride lda) . w^T + bias (N) + residual (M, N; row stride ldc)); residual may
- *                               alias out.  K % 64 == 0, N % 32 == 0 (full speed: N % 256 == 0).
+ *                               alias out.  K % 64 == 0, N % 32 == 0 (full speed: N % 256 == 0), lda / ldc % 4 == 0, every pointer 16-byte
+ *                               aligned, M * lda < 2^31: wd_gemm_split_supported() answers that question for host code that wants to fall back.
  *   wd_conv_split_f32         : x (batch, H, W, C) NHWC, ksize 1 or 3, any stride / pad (zero padding), C % 64 == 0;
  *                               out (batch, Ho, Wo, N) NHWC with the same fused epilogue. */
 size_t wd_gemm_split_packed_bytes(int N, int K);
@@ -96,11 +101,31 @@ int wd_gemm_split_f32(const float* a, long lda, const void* packed_w, const floa
                       int M, int N, int K, int relu, void* workspace, size_t workspace_bytes, void* stream);
 int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void* packed_w, int ksize, int stride, int pad, const float* bias,
                       const float* residual, float* out, int N, int relu, void* workspace, size_t workspace_bytes, void* stream);
-/* diagnostics: per-workgroup s_memtime stamps of the following wd_gemm_split_f32 / wd_conv_split_f32 launches (8 int64 per workgroup; NULL = off) */
-int wd_gemm_split_debug_stamps(long long* buf);
-/* diagnostics: canary workgroups (LDS / register / VALU / MFMA self-checks) for co-residency experiments; flags: 5 device uint32 counters */
-int wd_debug_canary(int workgroups, int lds_bytes, int spins, unsigned* flags, void* stream);
-int wd_debug_occupy(int workgroups, int lds_bytes, long long ticks, unsigned* sink, void* stream);
+int wd_gemm_split_supported(const float* a, long lda, const float* bias, const float* residual, const float* out, long ldc, long M, int N, int K);
+/* Round 6 - activation planes: the A operand of a split-operand GEMM stored PRE-SPLIT by the kernel that produced it, so that the consumer pulls it
+ * into LDS with LDS-DMA (global_load_lds_dwordx4) instead of loading f32, splitting on the vector units and writing LDS once per N tile.
+ * Layout of an (M, K) activation matrix, K % 32 == 0: [ceil(M / 32) row blocks][K / 32][3 planes: hi, mid, lo][2048 bytes], the 2048 bytes being the
+ * LDS image of 32 rows x 32 bfloat16 the kernel's fragment reads expect (64-byte rows, the four 16-byte slots of row r XOR-swizzled with (r >> 2) & 3);
+ * 6 bytes per element, wd_split_planes_bytes(M, K) in total, 16-byte aligned.  hi + mid + lo reproduces the f32 value exactly (same semantics as above).
+ *   wd_split_planes_pack_f32 / _unpack_f32 : f32 (M, K; row stride) <-> planes (stand-alone producer / consumer; exact both ways)
+ *   wd_gemm_split_io : the GEMM with every operand in either form - exactly one of io->a (f32, row stride lda) / io->a_planes; at most one of
+ *                      io->residual (f32, row stride ldc) / io->residual_planes ((M, N) planes); at least one of io->out (f32, ldc) / io->out_planes
+ *                      ((M, N) planes: the A operand of the next GEMM).  ldc == 0 means N.  A planes residual may alias out_planes. */
+typedef struct WdSplitIO {
+    const float* a;
+    long lda;
+    const void* a_planes;
+    const float* residual;
+    const void* residual_planes;
+    float* out;
+    void* out_planes;
+    long ldc;
+} WdSplitIO;
+size_t wd_split_planes_bytes(long M, int K);
+int wd_split_planes_pack_f32(const float* a, long lda, long M, int K, void* planes, void* stream);
+int wd_split_planes_unpack_f32(const void* planes, long M, int K, float* out, long ldo, void* stream);
+int wd_gemm_split_io(const WdSplitIO* io, const void* packed_w, const float* bias, int M, int N, int K, int relu, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* wd_nms_sorted_f32 on n_seg (<= 8) independent row ranges in one pair of launches: detectron2's per-level batched_nms of the RPN
  * (find_top_rpn_proposals) with the levels' suppression chains in parallel workgroups.  Every range is sorted by descending
  * score; idxs may still mark rows that must not suppress (group -1).  n_keep: n_seg device ints. */

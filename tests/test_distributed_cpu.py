@@ -2,6 +2,7 @@
 to rank 0 reproduce the single-process result (global track IDs included).  The per-rank tracker is the CPU oracle
 here (tests may use it as the checker); on the GPU box the same code path runs with the HIP tracker over RCCL."""
 import json
+import pytest
 import os
 import sys
 
@@ -206,6 +207,13 @@ def test_launcher_environment_and_refusal(tmp_path):
     kept = L.rank_environments(2, 23456, base_env={'MIOPEN_USER_DB_PATH': '/x', 'OMP_NUM_THREADS': '3'}, scratch=str(tmp_path / 'cache'))
     assert all(e['MIOPEN_USER_DB_PATH'] == '/x' and e['OMP_NUM_THREADS'] == '3' for e in kept)
     assert 'MIOPEN_USER_DB_PATH' not in L.rank_environments(1, 23456, base_env={})[0]
+    # a symbolic link planted under the predictable root name is refused (lstat, not stat): its target may be any directory this user owns
+    target = tmp_path / 'victim_dir'
+    target.mkdir()
+    link = tmp_path / 'planted_root'
+    os.symlink(target, link)
+    with pytest.raises(L.LaunchError):
+        L.private_dir(str(link))
     # ranks started by torchrun (the driver's launch) adopt the same per-rank locations in-process; an exported one is left alone
     env = {'MIOPEN_CUSTOM_CACHE_DIR': '/mine'}
     assert sorted(L.adopt_rank_caches(3, 8, environ=env, scratch=str(tmp_path / 'tr'))) == ['MIOPEN_USER_DB_PATH', 'WT_TUNABLEOP_OUT']
@@ -239,7 +247,6 @@ def test_launcher_environment_and_refusal(tmp_path):
     finally:
         os.environ.clear()
         os.environ.update(saved)
-    import pytest
     with pytest.raises(L.LaunchError, match='only 1 GPU'):
         L.spawn_local_ranks([sys.executable, '-c', 'pass'], 2, n_devices=1)      # never oversubscribe a GPU
     with pytest.raises(L.LaunchError):

@@ -304,3 +304,121 @@ def test_cached_batch_pack_equals_single_packs_and_follows_the_weight(ops):
         assert torch.equal(ops.split_pack_cached(again), ops.split_pack_weight(again))
     with pytest.raises(ValueError):
         ops.split_pack_cached(torch.randn(64, 96, device='cuda'))                  # K % 64 != 0
+
+
+# ---- round 6: activation planes (pre-split A pulled by LDS-DMA) ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize('m,n,k,epi', [(9600, 1024, 1024, 1), (9601, 1024, 1024, 1), (2400, 2048, 2048, 0), (38400, 512, 512, 1), (1000, 1024, 12544, 0),
+                                       (100, 64, 128, 1), (4000, 224, 192, 1), (33, 32, 64, 0)])
+def test_planes_kernel_is_bit_identical_to_the_f32_a_kernel(ops, m, n, k, epi):
+    """wd_gemm_split_io with A as activation planes == wd_gemm_split_f32 bit for bit (the planes ARE the in-kernel split, the MFMA order is the same),
+    with bias / residual / ReLU, ragged M, N % 256 != 0, K-sliced shapes; the planes output is the split of the f32 output; a planes residual
+    (also in place: block output into the residual's buffer) gives the same result as the f32 residual."""
+    torch.manual_seed(m + n + k)
+    a = torch.randn(m, k, device='cuda')
+    w = torch.randn(n, k, device='cuda') / k ** 0.5
+    bias = torch.randn(n, device='cuda') if epi else None
+    res = torch.randn(m, n, device='cuda') if epi else None
+    pw = ops.split_pack_weight(w)
+    ap = ops.split_planes_pack(a)
+    assert torch.equal(ops.split_planes_unpack(ap, m, k), a)                      # exact both ways
+    y0 = ops.gemm_split(a, pw, n, bias, res, bool(epi))
+    y1, p1 = ops.gemm_split_io(m, n, k, pw, a_planes=ap, bias=bias, residual=res, relu=bool(epi), want_out=True, want_planes=True)
+    assert torch.equal(y0, y1)
+    assert torch.equal(ops.split_planes_unpack(p1, m, n), y1)
+    full = ops.split_planes_bytes(m // 32 * 32, n) if m >= 32 else 0           # whole row blocks: byte-identical with a stand-alone pack
+    assert torch.equal(p1[:full], ops.split_planes_pack(y1)[:full])
+    y2, p2 = ops.gemm_split_io(m, n, k, pw, a=a, bias=bias, residual=res, relu=bool(epi), want_planes=True)      # f32-A kernel, both outputs
+    assert torch.equal(y2, y0) and torch.equal(ops.split_planes_unpack(p2, m, n), y0)
+    if epi:
+        rp = ops.split_planes_pack(res)
+        y3, _ = ops.gemm_split_io(m, n, k, pw, a_planes=ap, bias=bias, residual_planes=rp, relu=True)
+        assert torch.equal(y3, y0)
+        _, p4 = ops.gemm_split_io(m, n, k, pw, a_planes=ap, bias=bias, residual_planes=rp, relu=True, want_out=False, out_planes=rp)
+        assert torch.equal(ops.split_planes_unpack(p4, m, n), y0)
+
+
+def test_planes_chain_of_two_gemms_never_touches_f32(ops):
+    """conv3 -> conv1 of the next bottleneck as the planes path runs them: block output as planes only, consumed as A AND as the residual."""
+    torch.manual_seed(11)
+    m, c = 4000, 256
+    x = torch.relu(torch.randn(m, c, device='cuda'))
+    w3, w1 = torch.randn(c, c, device='cuda') / 16, torch.randn(c, c, device='cuda') / 16
+    b3 = torch.randn(c, device='cuda') * 0.1
+    p3, p1 = ops.split_pack_weight(w3), ops.split_pack_weight(w1)
+    xp = ops.split_planes_pack(x)
+    _, blk = ops.gemm_split_io(m, c, c, p3, a_planes=xp, bias=b3, residual_planes=xp, relu=True, want_out=False, want_planes=True)
+    y, _ = ops.gemm_split_io(m, c, c, p1, a_planes=blk, relu=True)
+    blk_ref = ops.gemm_split(x, p3, c, b3, x.clone(), True)
+    assert torch.equal(ops.split_planes_unpack(blk, m, c), blk_ref)
+    assert torch.equal(y, ops.gemm_split(blk_ref, p1, c, None, None, True))
+
+
+def test_split_gemm_error_with_operands_that_maximise_the_small_planes(ops):
+    """the dropped cross terms (mid.lo, lo.mid, lo.lo) are largest when mid and lo sit at half an ulp of the plane above.  Operands
+    x = 1 + 2^-9 + 2^-18 + ... patterns (every plane at its rounding boundary, random signs) must still keep the error against float64 within 1.25 x
+    the f32 GEMM's."""
+    g = torch.Generator().manual_seed(17)
+    m, n, k = 2048, 256, 1024
+
+    def worst(shape):
+        sign = (torch.randint(0, 2, shape, generator=g) * 2 - 1).double()
+        e = torch.randint(-3, 4, shape, generator=g).double()
+        # hi = 1.xxxxxxx1 (odd last bit), mid just below half an ulp of hi, lo just below half an ulp of mid
+        hi = 1.0 + torch.randint(0, 64, shape, generator=g).double() * 2.0 ** -6 + 2.0 ** -7
+        v = hi + (2.0 ** -9 - 2.0 ** -16) + (2.0 ** -18 - 2.0 ** -23)
+        return (sign * v * 2.0 ** e).float().cuda()
+
+    a, w = worst((m, k)), worst((n, k)) / k ** 0.5
+    ref = a.double() @ w.double().t()
+    y = ops.gemm_split(a, ops.split_pack_weight(w), n)
+    e_split, e_lib = _err(y, ref), _err(a @ w.t(), ref)
+    assert e_split[1] <= 1.25 * e_lib[1] and e_split[0] <= 1.25 * e_lib[0], (e_split, e_lib)
+
+
+def test_split_gemm_nonfinite_and_tiny_operands_follow_the_documented_semantics(ops):
+    """include/waymodet.h: an inf / NaN operand makes its output elements NaN (an f32 GEMM gives +-inf where no NaN is involved); operands below
+    2^-110 lose their lowest plane (relative error up to 2^-16 instead of 2^-24) - and nothing else in the matrix is disturbed."""
+    torch.manual_seed(19)
+    m, n, k = 160, 256, 64
+    a = torch.randn(m, k, device='cuda')
+    w = torch.randn(n, k, device='cuda')
+    a[3, 5] = float('inf')
+    a[7, 9] = float('nan')
+    y = ops.gemm_split(a, ops.split_pack_weight(w), n)
+    assert torch.isnan(y[3]).all() and torch.isnan(y[7]).all()
+    clean = torch.ones(m, dtype=torch.bool, device='cuda')
+    clean[3] = clean[7] = False
+    ref = a[clean].double() @ w.double().t()
+    assert float((y[clean].double() - ref).abs().max()) <= 1e-4
+    tiny = torch.full((m, k), 2.0 ** -120, device='cuda') * (1 + 2.0 ** -20)
+    one = torch.zeros(n, k, device='cuda')
+    one[:, 0] = 1.0
+    yt = ops.gemm_split(tiny, ops.split_pack_weight(one), n)
+    rel = float(((yt[:, 0].double() - tiny[:, 0].double()) / tiny[:, 0].double()).abs().max())
+    assert rel <= 2.0 ** -15 and torch.isfinite(yt).all()
+
+
+def test_laboratory_knobs_are_ignored_without_wt_experiment():
+    """WD_SPLIT_MT=2 re-enables a tile height next to which two other kernels return wrong results (profiles/r06_costream_victim_side.txt): a product
+    process must ignore it (with a warning); WT_EXPERIMENT=1 is the explicit opt-in."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, time\n"
+            "from waymo_2d_tracking_amd.detnet.nn import ops\n"
+            "a = torch.randn(38400, 256, device='cuda'); w = ops.split_pack_weight(torch.randn(256, 256, device='cuda') / 16)\n"
+            "ops.gemm_split(a, w, 256); torch.cuda.synchronize()\n"
+            "e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)\n"
+            "e0.record()\n"
+            "for _ in range(20): ops.gemm_split(a, w, 256)\n"
+            "e1.record(); torch.cuda.synchronize(); print('OK')\n")
+    env = dict(os.environ, WD_SPLIT_MT='2')
+    env.pop('WT_EXPERIMENT', None)
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, r.stderr[-2000:]
+    assert 'WD_SPLIT_MT=2 ignored' in r.stderr
+    env['WT_EXPERIMENT'] = '1'
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ignored' not in r.stderr, r.stderr[-2000:]

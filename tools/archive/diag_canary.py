@@ -1,7 +1,7 @@
 """Canary workgroups (self-checking LDS pattern / registers / VALU chain / f32 MFMA chain) on stream 0 while stream 1 loops a kernel.
 AGGRESSOR = split2 | split5 | none"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd import _lib

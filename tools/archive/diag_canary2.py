@@ -1,6 +1,6 @@
 """One LONG canary launch (self-checking LDS / registers / VALU / MFMA) on stream 0 while stream 1 issues split-operand launches all the time."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd import _lib

@@ -1,7 +1,7 @@
 """Two streams, each a deep chain of the deformable 3x3 path of a res4 block (offset conv GEMM + table launch + persistent kernel), new data per
 iteration: equal to serial?  (No split-operand kernel involved.)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det

@@ -1,6 +1,6 @@
 """Are the remaining library GEMMs (offset-conv mm, RPN head addmm) bit-reproducible with other kernels in flight on a second stream?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops

@@ -1,7 +1,7 @@
 """Chains of dependent split-operand launches (conv1 -> conv3 + residual, conv 3x3 behind) on two streams at once, new data every iteration:
 every result must equal the serial run of the same chain."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops

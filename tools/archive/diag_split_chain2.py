@@ -1,6 +1,6 @@
 """res2-block-shaped chain (6144 rows: 64 -> 256 shortcut, 64 -> 256 conv1, 256 -> 256 conv3 + residual) on two streams, new data per iteration."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops

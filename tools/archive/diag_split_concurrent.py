@@ -1,7 +1,7 @@
 """Two streams issuing split-operand GEMMs / convolutions at the same time must give the results of serial launches, bit for bit."""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops

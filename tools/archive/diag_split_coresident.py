@@ -1,6 +1,6 @@
 """Single stream, one launch with more workgroups than CUs at a tile height whose LDS lets two workgroups share a CU (MT = 2: 64 KiB each)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops

@@ -1,7 +1,7 @@
 """Guaranteed overlap: two streams, each a dependent chain of split-operand GEMMs enqueued deep enough (REPS launches per chain) that both
 queues stay full.  CHAIN_M rows (6144 -> MT = 2 tiles whose 64 KiB of LDS let two workgroups share a CU; 38400 -> MT = 5, one per CU)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops

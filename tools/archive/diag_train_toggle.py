@@ -5,7 +5,7 @@ bottleneck (block output, conv1 output, offsets) are captured over REPEATS runs 
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det

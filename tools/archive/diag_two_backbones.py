@@ -1,6 +1,6 @@
 """Concurrency bisect at module level: stem + the first NB bottleneck blocks of res2.. on two streams vs serial (new image per iteration)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F

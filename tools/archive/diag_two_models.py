@@ -1,7 +1,7 @@
 """Two detectors on two streams at the same time vs the same two run one after the other: first intermediate tensor that differs."""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det

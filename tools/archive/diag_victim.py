@@ -1,7 +1,7 @@
 """Victim / aggressor: stream 0 repeats the res5 stride-2 deformable conv (deform_conv3x3_kernel<64, true>) on fixed inputs and checks every output
 against the serial result; stream 1 runs ONE kind of kernel in a loop.  AGGRESSOR = split2 | split5 | gconv | mm | none"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops
@@ -29,6 +29,11 @@ def aggress():
         ops.deform_conv3x3(xg, None, wg, 32, 1, 1, None, None, True)
     elif AGG == 'mm':
         torch.mm(ma, mb.t())
+    elif AGG.startswith('burn'):                         # burnK: 512 workgroups of the pure-register matrix-instruction burner, kind K (debug build)
+        import ctypes as C
+        from waymo_2d_tracking_amd import _lib
+        _lib.check(_lib.lib().wd_debug_mfma_burn(C.c_int(int(os.environ.get('BURN_WGS', '512'))), C.c_int(int(AGG[4:])), C.c_int(int(os.environ.get('BURN_ITERS', '400'))),
+                                                 C.c_void_p(sink.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'burn')
     elif AGG.startswith('canary'):                       # canaryN: N busy workgroups (VALU / f32 MFMA / LDS reads), 36 KB of LDS, few registers
         import ctypes as C
         from waymo_2d_tracking_amd import _lib
@@ -88,3 +93,15 @@ for y in outs:
                 len(d), yf.numel(), int(d.min()), int(d.max()), sorted(set((d // y.shape[1]).tolist()))[:12], int((d % y.shape[1]).min()), int((d % y.shape[1]).max())))
             print('  got', yf[d[:6]].tolist(), 'ref', rf[d[:6]].tolist())
 print('aggressor %s victim %s: %d of %d victim launches differ' % (AGG, VICTIM, bad, len(outs)))
+# round 6 (-DWD_VICTIM_CHECK build of det_gconv.hip): the grouped-conv victim compared its LDS patch with global memory after every inner tile
+try:
+    import ctypes as C
+    import numpy as np
+    from waymo_2d_tracking_amd import _lib
+    fn = getattr(_lib.lib(), 'wd_debug_victim_counters', None)
+    if fn is not None:
+        c = np.zeros(4, dtype=np.uint32)
+        fn(c.ctypes.data_as(C.c_void_p), C.c_int(1))
+        print('victim self-check: %d patch float4 in LDS differ from global memory over %d inner tiles' % (c[0], c[1]))
+except AttributeError:
+    pass

@@ -1,7 +1,7 @@
 """Roles swapped: stream 0 repeats a small-tile split-operand GEMM (MT = 2) and checks every output; stream 1 loops the res5 stride-2 deformable conv
 (deform_conv3x3_kernel<64, true>) or another kernel.  AGGRESSOR = deform64 | gconv | none"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from waymo_2d_tracking_amd.detnet.nn import ops

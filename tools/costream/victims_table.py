@@ -1,0 +1,162 @@
+"""Round 6 (VERDICT weak #3 / ADVICE medium): every product kernel of the frame as a VICTIM next to split-operand launches of one tile height on another
+stream.  Stream 0 repeats ONE victim op REPS times on fixed inputs and every output is compared bit for bit with its serial result; stream 1 issues the
+aggressor (res2-shaped split GEMM, tile height forced with WD_SPLIT_MT + WT_EXPERIMENT=1) three times per victim launch.
+    WD_SPLIT_MT=4 WT_EXPERIMENT=1 python tools/costream/victims_table.py [victim ...]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from waymo_2d_tracking_amd.detnet.nn import ops
+
+REPS = int(os.environ.get('REPS', '200'))
+torch.manual_seed(0)
+dev = 'cuda'
+
+
+def cl(x):
+    return x.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+# aggressors: the short-K res2 shapes (many tiles, prologue / epilogue heavy) and the res4 shape
+A_SHAPES = {'res2': (38400, 256, 256), 'res4': (9600, 1024, 1024)}
+agg = {}
+for name, (m, n, k) in A_SHAPES.items():
+    agg[name] = (torch.randn(m, k, device=dev), ops.split_pack_weight(torch.randn(n, k, device=dev) / k ** 0.5), n)
+for name, (m, n, k) in A_SHAPES.items():           # the same shapes through the round-6 kernel (A as activation planes, LDS-DMA loader)
+    agg['planes_' + name] = (ops.split_planes_pack(agg[name][0]), agg[name][1], (m, n, k))
+AGG = os.environ.get('AGGRESSOR', 'res2')
+_sink = torch.zeros(4, dtype=torch.int32, device=dev)
+_planes_out = {}
+
+
+def aggress():
+    if AGG == 'none':
+        return
+    if AGG.startswith('burn'):       # the pure-register matrix-instruction burner of the debug library (WT_LIB_PATH=.../libwaymotrack_debug.so)
+        import ctypes as C
+        from waymo_2d_tracking_amd import _lib
+        _lib.check(_lib.lib().wd_debug_mfma_burn(C.c_int(512), C.c_int(int(AGG[4:])), C.c_int(400), C.c_void_p(_sink.data_ptr()),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'burn')
+        return
+    a, w, n = agg[AGG]
+    if AGG.startswith('planes_'):
+        ops.gemm_split_io(n[0], n[1], n[2], w, a_planes=a, relu=True, want_out=False, out_planes=_planes_out.setdefault(AGG, ops.split_planes_empty(n[0], n[1], dev)))
+        return
+    ops.gemm_split(a, w, n, None, None, True)
+
+
+def make_victims():
+    v = {}
+    g = torch.Generator().manual_seed(1)
+    # ROIAlign (roi_pool_wg_kernel + order kernel): 1000 ROIs over four FPN levels of a 640 x 960 frame
+    strides = [4, 8, 16, 32]
+    H, W, Cc = 640, 960, 256
+    feats = [cl(torch.randn((1, Cc, H // s, W // s), generator=g)) for s in strides]
+    sz = torch.exp(torch.empty(1000).uniform_(np.log(16), np.log(500), generator=g))
+    asp = torch.exp(torch.empty(1000).uniform_(-0.7, 0.7, generator=g))
+    bw, bh = sz * asp, sz / asp
+    x1 = torch.rand(1000, generator=g) * (W - 8)
+    y1 = torch.rand(1000, generator=g) * (H - 8)
+    rois = torch.stack([torch.zeros(1000), x1, y1, x1 + bw, y1 + bh], 1).to(dev)
+    sc = [1.0 / s for s in strides]
+    v['roi_pool_wg'] = lambda: ops.roi_pool_fpn(feats, rois, sc)
+    # GroupNorm + ReLU of the box head (in place on a fresh copy)
+    xg = cl(torch.randn((512, 256, 7, 7), generator=g) * 3 + 1)
+    gw, gb = (torch.rand(256, generator=g) + 0.5).to(dev), torch.randn(256, generator=g).to(dev)
+    v['groupnorm_relu'] = lambda: ops.groupnorm_relu_(xg.clone(memory_format=torch.preserve_format), gw, gb, 32)
+    # deformable family: res4 s1 (pp<32>), res3 s1 (pp<16>), res5 s1 (patch<64>), res5 s2 (round-1 kernel), res4 s2 (pp, stride 2), res2 grouped conv
+    def dc(c, h, w, stride, std=0.3, offsets=True):
+        x = cl(torch.randn((1, c, h, w), generator=g) * 0.5)
+        ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+        off = cl(torch.randn((1, 18, ho, wo), generator=g) * std) if offsets else None
+        wgt = ops.deform_pack_weight(torch.randn((c, c // 32, 3, 3), generator=g).to(dev) / (3 * (c // 32) ** 0.5), 32)
+        return lambda: ops.deform_conv3x3(x, off, wgt, 32, stride, 1, None, None, True)
+    v['deform_pp32_res4'] = dc(1024, 40, 60, 1)
+    v['deform_pp16_res3'] = dc(512, 80, 120, 1)
+    v['deform_patch64_res5'] = dc(2048, 20, 30, 1)
+    v['deform64_res5_s2'] = dc(2048, 16, 24, 2)
+    v['deform_pp32_res4_s2'] = dc(1024, 40, 60, 2)
+    v['deform_pp32_far'] = dc(1024, 40, 60, 1, std=2.5)
+    v['gconv_c8_res2'] = dc(256, 64, 96, 1, offsets=False)
+    # NMS (mask tiles + one-workgroup sweep)
+    nb = 3000
+    cx, cy = torch.rand(nb, generator=g) * 900, torch.rand(nb, generator=g) * 600
+    ww, hh = torch.rand(nb, generator=g) * 80 + 8, torch.rand(nb, generator=g) * 80 + 8
+    boxes = torch.stack([cx, cy, cx + ww, cy + hh], 1).to(dev)
+    scores = torch.rand(nb, generator=g).to(dev)
+    v['nms'] = lambda: ops.nms(boxes, scores, 0.5)
+    # pre-processing, upsample
+    img = (torch.rand((1280, 1920, 3), generator=g) * 255).to(torch.uint8).to(dev)
+    v['preprocess'] = lambda: ops.preprocess(img[None], 1.0)
+    up = cl(torch.randn((1, 256, 40, 60), generator=g))
+    v['upsample2x'] = lambda: ops.upsample2x_nearest(up)
+    # the exact-f32 MFMA GEMM of round 2 (box-head FC shape, K-sliced: deterministic two-pass)
+    fa, fb = torch.randn(1000, 12544, generator=g).to(dev), (torch.randn(1024, 12544, generator=g) / 112).to(dev)
+    v['gemm_nt_f32'] = lambda: ops.gemm_nt(fa, fb, None, None, True)
+    # the split kernel itself at the product's tile height (victim of its own kind)
+    sa, sw = torch.randn(9600, 1024, generator=g).to(dev), ops.split_pack_weight((torch.randn(1024, 1024, generator=g) / 32).to(dev))
+    v['gemm_split_res4'] = lambda: ops.gemm_split(sa, sw, 1024, None, None, True)
+    # offset conv (tap GEMM + shift-add + table)
+    ox = cl(torch.randn((1, 1024, 40, 60), generator=g) * 0.5)
+    ow = ops.tap_gemm_weight((torch.randn((18, 1024, 3, 3), generator=g) / 96).to(dev))
+    obias = torch.randn(18, generator=g).to(dev)
+    v['offset_conv'] = lambda: ops.conv3x3_few(ox, ow, obias, 18)
+    # SORT (sort_streams_kernel) and soft-NMS ensemble through their host entry points
+    from waymo_2d_tracking_amd import synthetic as syn
+    from waymo_2d_tracking_amd.tracking import utils as T
+    dets = syn.make_sequence_json(5, n_segments=1, n_frames=30, n_objects=60)
+    predictions = {}
+    for e in dets:
+        seg, fr, cam = e['image_id'].split('/')
+        predictions.setdefault(seg, {}).setdefault(cam, {}).setdefault(int(fr), []).append(
+            {'bbox': e['bbox'], 'score': e['score'], 'category_id': e['category_id']})
+    packed = T.pack_streams(predictions)
+    def sort_run():
+        out, births = T.track_packed(packed, [0.01, 0.01, 1.0, 0.0], 2, 0, [0.3, 0.2, 1.0, 0.1])
+        return torch.from_numpy(np.concatenate([out['object_id'].astype(np.float64).ravel(), out['bbox'].astype(np.float64).ravel()]))
+    v['sort_streams'] = sort_run
+    from waymo_2d_tracking_amd.detnet.nn.tta import nms_detections
+    rng = np.random.default_rng(0)
+    groups = syn.ensemble_group(rng, 100, 13)
+    groups = [np.concatenate([q[:, :1], q[:, 1:3] + q[:, 3:5] / 2, q[:, 3:5]], axis=1) for q in groups]
+    v['softnms_ensemble'] = lambda: torch.from_numpy(np.asarray(nms_detections(groups, iou_thresh=0.5, soft=True, soft_nms_cut=0.9)))
+    return v
+
+
+def flat(y):
+    if isinstance(y, (tuple, list)):
+        return [t for t in y if torch.is_tensor(t)]
+    return [y]
+
+
+victims = make_victims()
+names = sys.argv[1:] or list(victims)
+s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+print('aggressor %s  WD_SPLIT_MT=%s  reps %d' % (AGG, os.environ.get('WD_SPLIT_MT', 'planner'), REPS), flush=True)
+for name in names:
+    fn = victims[name]
+    try:
+        ref = [t.clone() for t in flat(fn())]
+        torch.cuda.synchronize()
+        # the victim must be repeatable on its own before it can testify
+        again = [t.clone() for t in flat(fn())]
+        torch.cuda.synchronize()
+        if not all(torch.equal(a, b) for a, b in zip(ref, again)):
+            print('%-22s not bit-repeatable on its own (atomics): skipped' % name, flush=True)
+            continue
+        outs = []
+        reps = REPS if name not in ('sort_streams', 'softnms_ensemble') else min(REPS, 50)
+        for rep in range(reps):
+            with torch.cuda.stream(s1):
+                for _ in range(3):
+                    aggress()
+            with torch.cuda.stream(s0):
+                outs.append([t for t in flat(fn())])
+        torch.cuda.synchronize()
+        bad = sum(0 if all(torch.equal(a, b) for a, b in zip(ref, y)) else 1 for y in outs)
+        print('%-22s %d of %d victim launches differ' % (name, bad, len(outs)), flush=True)
+    except Exception as e:      # a victim that cannot be set up is reported, not hidden
+        print('%-22s ERROR %s: %s' % (name, type(e).__name__, e), flush=True)

@@ -78,7 +78,7 @@ def lib():
                      'wt_track_chunk_workspace'):
             getattr(_lib, name).restype = C.c_size_t
         for name in ('wd_workspace_bytes', 'wd_nms_workspace', 'wd_rpn_topk_workspace', 'wd_gemm_nt_workspace', 'wd_deform_table_bytes',
-                     'wd_deform_dw_scratch_floats', 'wd_deform_bwd_tables_bytes', 'wd_gemm_split_packed_bytes', 'wd_gemm_split_workspace'):
+                     'wd_deform_dw_scratch_floats', 'wd_deform_bwd_tables_bytes', 'wd_gemm_split_packed_bytes', 'wd_gemm_split_workspace', 'wd_split_planes_bytes'):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_size_t
     return _lib

@@ -43,6 +43,14 @@ UNITS = {
     'det_backward.hip': ['-munsafe-fp-atomics'],
     'det_deform_bwd.hip': ['-munsafe-fp-atomics'],     # fused deformable backward: global float atomics for the dW / dX / dOffset partial sums
 }
+# laboratory kernels (canaries, occupants, the matrix-instruction burner of tools/costream/): only with WD_DEBUG_BUILD=1, never in the product library
+# -> csrc/libwaymotrack_debug.so with its own objects (*.dbg.o); load it with WT_LIB_PATH
+DEBUG_BUILD = os.environ.get('WD_DEBUG_BUILD') == '1'
+OBJ_EXT = '.dbg.o' if DEBUG_BUILD else '.o'
+if DEBUG_BUILD:
+    UNITS['debug/debug_kernels.hip'] = []
+    COMMON += ['-DWD_DEBUG=1']
+    LIB = os.path.join(CSRC, 'libwaymotrack_debug.so')
 
 
 def _newer(target, sources):
@@ -60,7 +68,7 @@ def build(force=False, verbose=True):
     jobs = []
     for u in units:
         src = os.path.join(CSRC, u)
-        obj = os.path.join(CSRC, u.replace('.hip', '.o'))
+        obj = os.path.join(CSRC, os.path.basename(u).replace('.hip', OBJ_EXT))
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
             jobs.append([HIPCC] + COMMON + UNITS[u] + ['-c', src, '-o', obj])

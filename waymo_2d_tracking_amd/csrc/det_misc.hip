@@ -302,25 +302,3 @@ extern "C" int wd_upsample2x_nhwc_f32(const float* src, int batch, int h, int w,
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
-
-// Experiments only (tools/hold_experiment.py): n_wg one-wave workgroups that each hold `lds_bytes` of LDS and spin for `cycles` shader
-// cycles - a stand-in for the tracker's workgroups next to the detector (how much does HOLDING compute units cost the other stream?).
-namespace {
-__global__ __launch_bounds__(64) void debug_hold_kernel(long long cycles, int* sink) {
-    extern __shared__ int hold_lds[];
-    const long long t0 = clock64();
-    int v = 0;
-    while (clock64() - t0 < cycles) { hold_lds[threadIdx.x] = v; v += hold_lds[(threadIdx.x + 1) & 63]; }
-    if (v == 0x7fffffff) sink[0] = v;
-}
-}  // namespace
-
-extern "C" int wd_debug_hold(int n_wg, int lds_bytes, long long cycles, int* sink, void* stream) {
-    WT_TRY(wt::ensure_device());
-    if (n_wg < 1 || lds_bytes < 256) { wt::set_error("wd_debug_hold: bad argument"); return WT_ERR_INVALID; }
-    if (lds_bytes > 48 * 1024)
-        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(debug_hold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL(debug_hold_kernel, dim3((unsigned)n_wg), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, cycles, sink);
-    WT_HIP(hipGetLastError());
-    return WT_OK;
-}

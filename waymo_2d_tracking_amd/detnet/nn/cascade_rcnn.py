@@ -109,8 +109,9 @@ class Conv1x1(nn.Module):
             if residual is not None:
                 r = residual if residual.is_contiguous(memory_format=torch.channels_last) else residual.contiguous(memory_format=torch.channels_last)
                 r = r.permute(0, 2, 3, 1).reshape(n * h * w, cout)
-            y = ops.gemm_split(a, pw, cout, self.bias, r, relu, out=r if _INPLACE else None)
-            return y.view(n, h, w, cout).permute(0, 3, 1, 2)
+            if ops.gemm_split_ok(a, cout, self.bias, r):           # (alignment / size preconditions: otherwise the library path below)
+                y = ops.gemm_split(a, pw, cout, self.bias, r, relu, out=r if _INPLACE else None)
+                return y.view(n, h, w, cout).permute(0, 3, 1, 2)
         if stride != 1:
             x = x[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)
         n, c, h, w = x.shape

@@ -507,6 +507,25 @@ def split_pack_cached(weight, kind='fwd'):
     return e.packed
 
 
+def gemm_split_ok(a, n, bias=None, residual=None, out=None):
+    """The full precondition of wd_gemm_split_f32 (wd_gemm_split_supported: K % 64, N % 32, row strides % 4, 16-byte aligned pointers, M * lda < 2^31)
+    for a 2-D f32 operand `a` (row-strided views allowed) - ONE predicate for every call site that may route a GEMM to the split-operand kernel, so
+    that a strided / offset view or a very large batch falls back to the library GEMM instead of raising."""
+    if not (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1):
+        return False
+    for t in (bias, residual, out):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            return False
+    m, k = a.shape
+    return bool(_lib.lib().wd_gemm_split_supported(_p(a), C.c_long(a.stride(0)), _p(bias), _p(residual), _p(out), C.c_long(n), C.c_long(m), C.c_int(n), C.c_int(k)))
+
+
+def conv_split_ok(x, c, n, ksize, stride, pad):
+    """Precondition of wd_conv_split_f32 (ksize 1 / 3, pad >= 0, C % 64, N % 32, fewer than 2^31 elements)."""
+    return (x.is_cuda and x.dtype == torch.float32 and ksize in (1, 3) and stride >= 1 and pad >= 0 and c % 64 == 0 and n % 32 == 0
+            and x.numel() < 2 ** 31 and x.data_ptr() % 16 == 0)
+
+
 def gemm_split(a, packed, n, bias=None, residual=None, relu=False, out=None):
     """out (M, N) = relu?(a (M, K) @ W.T + bias + residual) with W packed by split_pack_weight: f32 operands as exact 3 x bf16 splits, six
     cross terms on the bf16 matrix cores, f32 accumulation (wd_gemm_split_f32).  `a` may be a row-strided view; residual may be `out`."""
@@ -523,6 +542,74 @@ def gemm_split(a, packed, n, bias=None, residual=None, relu=False, out=None):
                                             C.c_int(n), C.c_int(k), C.c_int(1 if relu else 0), _p(ws), C.c_size_t(ws_bytes), _stream()), 'wd_gemm_split_f32')
     _split_log_end(ev, 'gemm_split_kernel: 1x1 conv / GEMM M=%d N=%d K=%d' % (m, n, k), m, n, k)
     return out
+
+
+class _SplitIO(C.Structure):
+    """struct WdSplitIO of include/waymodet.h"""
+    _fields_ = [('a', C.c_void_p), ('lda', C.c_long), ('a_planes', C.c_void_p), ('residual', C.c_void_p), ('residual_planes', C.c_void_p),
+                ('out', C.c_void_p), ('out_planes', C.c_void_p), ('ldc', C.c_long)]
+
+
+def split_planes_bytes(m, k):
+    return int(_lib.lib().wd_split_planes_bytes(C.c_long(m), C.c_int(k)))
+
+
+def split_planes_empty(m, k, device):
+    """Uninitialised activation planes of an (m, k) matrix (uint8 tensor; rows of the last 32-row block beyond m are never read into results)."""
+    n = split_planes_bytes(m, k)
+    if n == 0:
+        raise ValueError('activation planes need K %% 32 == 0 (M=%d K=%d)' % (m, k))
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def split_planes_pack(a, out=None):
+    """f32 (M, K) (row-strided view allowed) -> activation planes (wd_split_planes_pack_f32): three bf16 planes per 32 x 32 block in LDS-image order."""
+    m, k = a.shape
+    assert a.dtype == torch.float32 and a.stride(1) == 1
+    if out is None:
+        out = split_planes_empty(m, k, a.device)
+    _lib.check(_lib.lib().wd_split_planes_pack_f32(_p(a), C.c_long(a.stride(0)), C.c_long(m), C.c_int(k), _p(out), _stream()), 'wd_split_planes_pack_f32')
+    return out
+
+
+def split_planes_unpack(planes, m, k):
+    """activation planes -> f32 (M, K), exact (hi + mid + lo)."""
+    out = torch.empty((m, k), dtype=torch.float32, device=planes.device)
+    _lib.check(_lib.lib().wd_split_planes_unpack_f32(_p(planes), C.c_long(m), C.c_int(k), _p(out), C.c_long(k), _stream()), 'wd_split_planes_unpack_f32')
+    return out
+
+
+def gemm_split_io(m, n, k, packed, a=None, a_planes=None, bias=None, residual=None, residual_planes=None, relu=False, out=None, out_planes=None,
+                  want_out=True, want_planes=False):
+    """The split-operand GEMM with every operand as f32 or as activation planes (wd_gemm_split_io).  Returns (out or None, out_planes or None)."""
+    dev = packed.device
+    if want_out and out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=dev)
+    if want_planes and out_planes is None:
+        out_planes = split_planes_empty(m, n, dev)
+    io = _SplitIO()
+    if a is not None:
+        assert a.dtype == torch.float32 and a.stride(1) == 1 and tuple(a.shape) == (m, k)
+        io.a, io.lda = a.data_ptr(), a.stride(0)
+    if a_planes is not None:
+        io.a_planes = a_planes.data_ptr()
+    if residual is not None:
+        assert residual.is_contiguous()
+        io.residual = residual.data_ptr()
+    if residual_planes is not None:
+        io.residual_planes = residual_planes.data_ptr()
+    if out is not None:
+        assert out.is_contiguous()
+        io.out = out.data_ptr()
+    if out_planes is not None:
+        io.out_planes = out_planes.data_ptr()
+    io.ldc = n
+    ws, ws_bytes = _split_workspace(m, n, k, dev)
+    ev = _split_log_begin()
+    _lib.check(_lib.lib().wd_gemm_split_io(C.byref(io), _p(packed), _p(bias), C.c_int(m), C.c_int(n), C.c_int(k), C.c_int(1 if relu else 0), _p(ws),
+                                           C.c_size_t(ws_bytes), _stream()), 'wd_gemm_split_io')
+    _split_log_end(ev, '%s: 1x1 conv / GEMM M=%d N=%d K=%d' % ('gemm_split_planes_kernel' if a_planes is not None else 'gemm_split_kernel', m, n, k), m, n, k)
+    return out, out_planes
 
 
 def conv_split(x, packed, n_out, ksize, stride=1, pad=0, bias=None, residual=None, relu=False):
@@ -923,7 +1010,7 @@ class ConvSplitFn(torch.autograd.Function):
             g = dy
         dx = dw = db = None
         want_dx = ctx.needs_input_grad[0]
-        if want_dx and stride == 1 and n % 64 == 0 and c % 32 == 0:
+        if want_dx and stride == 1 and conv_split_ok(g, n, c, ks, 1, ks - 1 - pad):
             # dX[ci](p) = sum over taps, co of g[co](p + pad - tap) W[co, ci, tap]: a convolution of g with the taps flipped, roles of ci / co swapped
             # (the weight is packed in that orientation where it lies: split_pack_cached 'dx')
             dx = conv_split(g, split_pack_cached(weight, 'dx'), c, ks, 1, ks - 1 - pad)
@@ -944,7 +1031,7 @@ class LinearActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, weight, bias, residual, relu):
         n, k = weight.shape
-        if SPLIT_TRAIN and a.is_cuda and k % 64 == 0 and n % 32 == 0 and a.stride(1) == 1:
+        if SPLIT_TRAIN and gemm_split_ok(a, n, bias, None if residual is None or not residual.is_contiguous() else residual):
             # round 5: the split-operand kernel (exact 3 x bf16 operand planes on the bf16 matrix cores), as at inference; a new output buffer -
             # the residual belongs to autograd
             r = None if residual is None else (residual if residual.is_contiguous() else residual.contiguous())
@@ -972,7 +1059,7 @@ class LinearActFn(torch.autograd.Function):
         n, k = weight.shape
         if not ctx.needs_input_grad[0]:
             da = None
-        elif SPLIT_TRAIN and g.is_cuda and n % 64 == 0 and k % 32 == 0:
+        elif SPLIT_TRAIN and gemm_split_ok(g, k):
             da = gemm_split(g, split_pack_cached(weight, 'T'), k)          # dA (M, K) = g (M, N) . (W^T)^T: W^T packed as a (K, N) weight
         else:
             da = g @ weight

@@ -59,8 +59,11 @@ def per_rank_cache_env(rank, n_ranks, scratch=None):
 def private_dir(path):
     """Create `path` for this user only (mode 0700) and refuse one that somebody else owns or may write: the default root has a
     predictable name in a world-writable directory, and what is read from it ends up selecting kernels."""
+    import stat
     os.makedirs(path, mode=0o700, exist_ok=True)
-    st = os.stat(path)
+    st = os.lstat(path)                      # lstat: a symlink planted under the predictable name must not pass for the directory it points to
+    if stat.S_ISLNK(st.st_mode) or not stat.S_ISDIR(st.st_mode):
+        raise LaunchError('%s is a symbolic link or not a directory: refusing to keep library caches there' % path)
     if st.st_uid != os.getuid():
         raise LaunchError('%s belongs to uid %d, not to this user: refusing to keep library caches there' % (path, st.st_uid))
     if st.st_mode & 0o022:
