@@ -52,22 +52,44 @@ def deform_conv3x3(x, offset, weight, groups, stride, pad):
     return F.conv2d(col, wt, None, 1, 0, 1, groups)
 
 
-def bottleneck(b, x):
+def block_decisions(relu1, offset, relu2, relu3, stride):
+    """The DISCRETE decisions of one bottleneck block, in a form two runs can compare exactly: the three ReLU masks (conv1, conv2, block output; from
+    the post-ReLU maps) and, for a deformable block, the bilinear cell (floor of the sampling position) of every (pixel, tap, axis).  A gradient is a
+    piecewise-smooth function of the forward values: two runs whose decisions agree differ by rounding only, a run whose decision fell the other way
+    (a ReLU input or a sampling position within float32 noise of the boundary) differs by a finite step (tests/test_gpu_detector.py)."""
+    d = {'relu1': (relu1.detach() > 0).cpu(), 'relu2': (relu2.detach() > 0).cpu(), 'relu3': (relu3.detach() > 0).cpu(), 'cells': None}
+    if offset is not None:
+        off = offset.detach().double().cpu()
+        n, _, ho, wo = off.shape
+        ys = torch.arange(ho, dtype=torch.float64).view(1, ho, 1) * stride - 1
+        xs = torch.arange(wo, dtype=torch.float64).view(1, 1, wo) * stride - 1
+        cells = []
+        for k in range(9):
+            cells.append(torch.floor(ys + k // 3 + off[:, 2 * k]))
+            cells.append(torch.floor(xs + k % 3 + off[:, 2 * k + 1]))
+        d['cells'] = torch.stack(cells, 1).to(torch.int32)
+    return d
+
+
+def bottleneck(b, x, record=None):
     sc = x if b.shortcut is None else conv1x1(b.shortcut, x, stride=b.stride)
-    out = conv1x1(b.conv1, x, relu=True)
-    offset = convbn(b.conv2_offset, out) if b.deform else None
-    out = deform_conv3x3(out, offset, b.conv2_weight, 32, b.stride, 1)
-    out = F.relu(out * b.conv2_scale.to(x.dtype).view(1, -1, 1, 1) + b.conv2_bias.to(x.dtype).view(1, -1, 1, 1))
-    return conv1x1(b.conv3, out, relu=True, residual=sc)
+    out1 = conv1x1(b.conv1, x, relu=True)
+    offset = convbn(b.conv2_offset, out1) if b.deform else None
+    out = deform_conv3x3(out1, offset, b.conv2_weight, 32, b.stride, 1)
+    out2 = F.relu(out * b.conv2_scale.to(x.dtype).view(1, -1, 1, 1) + b.conv2_bias.to(x.dtype).view(1, -1, 1, 1))
+    out3 = conv1x1(b.conv3, out2, relu=True, residual=sc)
+    if record is not None:
+        record.append(block_decisions(out1, offset, out2, out3, b.stride))
+    return out3
 
 
-def backbone(bb, x):
+def backbone(bb, x, record=None):
     x = convbn(bb.stem, x, relu=True)
     x = F.max_pool2d(x, 3, 2, 1)
     feats = []
     for stage in (bb.res2, bb.res3, bb.res4, bb.res5):
         for blk in stage:
-            x = bottleneck(blk, x)
+            x = bottleneck(blk, x, record)
         feats.append(x)
     prev = conv1x1(bb.lateral[3], feats[3])
     outs = [convbn(bb.output[3], prev)]
@@ -314,7 +336,8 @@ def losses(model, image_bgr, gt_boxes, gt_classes, dtype=torch.float64, rpn_batc
     ph, pw = (32 - img_h % 32) % 32, (32 - img_w % 32) % 32
     if ph or pw:
         x = F.pad(x, (0, pw, 0, ph))
-    feats = backbone(model.backbone, x)
+    block_record = [] if return_intermediates else None
+    feats = backbone(model.backbone, x, block_record)
     r = model.rpn
     logits_l, deltas_l, anchors_l, boxes_l, scores_l, lvl_l = [], [], [], [], [], []
     for l, f in enumerate(feats):
@@ -346,7 +369,7 @@ def losses(model, image_bgr, gt_boxes, gt_classes, dtype=torch.float64, rpn_batc
     target = torch.cat((torch.ones(len(pos), dtype=dtype), torch.zeros(len(neg), dtype=dtype)))
     out['loss_rpn_cls'] = F.binary_cross_entropy_with_logits(logits[sel], target, reduction='sum') / rpn_batch
     out['loss_rpn_loc'] = (deltas[pos] - tgt_d).abs().sum() / rpn_batch
-    inter = dict(proposals=proposals, rpn_pos=pos, rpn_neg=neg)
+    inter = dict(proposals=proposals, rpn_pos=pos, rpn_neg=neg, blocks=block_record)
     with torch.no_grad():
         boxes = torch.cat((proposals, gt_boxes))
         idx, lab = _matcher(_iou_matrix(gt_boxes, boxes), [0.5], [0, 1], False)

@@ -99,21 +99,60 @@ def test_tta_x15_hflip_roundtrip(models):
     assert abs(sum(len(a) for a in unfused[0]) - n) <= max(2, n // 10)
 
 
+def _flipped_blocks(names, dec_a, dec_b):
+    """Blocks whose DISCRETE decisions differ between two executions (oracle.detector_ref.block_decisions: the three ReLU masks and the bilinear cell of every
+    (pixel, tap, axis) of the deformable sampling).  A gradient is a piecewise-smooth function of the forward values: where the decisions agree, two
+    executions differ by rounding; a decision that fell the other way (a ReLU input / a sampling position within float32 noise of its boundary) moves the
+    tensors of ITS block by a finite step and, through the gradient that flows on, the blocks in front of it by a smaller one."""
+    flipped = []
+    for name, a, b in zip(names, dec_a, dec_b):
+        n = sum(int((a[k] != b[k]).sum()) for k in ('relu1', 'relu2', 'relu3'))
+        if a['cells'] is not None:
+            n += int((a['cells'] != b['cells']).sum())
+        if n:
+            flipped.append(name)
+    return flipped
+
+
+def _check_gradient_tiers(rel, names, flipped, tight, max_flipped=3):
+    """Evidence-based bounds (round 6; measured with tools/train_flip_check.py, gpurun_out/r06_flip_check.txt): tensors of a block with a demonstrated flip
+    <= 3e-2 (seen 8.9e-3), tensors of blocks in FRONT of a flipped block (their incoming gradient passed through it) <= 1e-2 (seen 6e-3 - 8e-3 in round
+    5), EVERY other tensor <= `tight` (seen without a flip: 2.3e-3 against float64); at most `max_flipped` flipped blocks (float32 against float64: res4.13 in every run, res4.27 in
+    about half; two float32 graphs whose epilogues round differently - fused multiply-add against multiply, then add - disagree in more places: 2 - 5
+    blocks seen)."""
+    assert len(flipped) <= max_flipped, flipped
+    order = {n: i for i, n in enumerate(names)}
+    last = max([order[f] for f in flipped], default=-1)
+    for n, e in rel.items():
+        blk = next((b for b in names if n.startswith('backbone.' + b + '.')), None)
+        if blk in flipped:
+            bound = 3e-2
+        elif blk is not None and order[blk] < last:
+            bound = 1e-2
+        else:
+            bound = tight
+        assert e <= bound, (n, e, bound, flipped)
+    ordered = sorted(rel.values())
+    assert ordered[len(ordered) // 2] <= 1e-3, ordered[len(ordered) // 2]
+
+
+def _block_names(model):
+    import re
+    return [n for n, _ in model.backbone.named_modules() if re.fullmatch(r'res\d\.\d+', n)]
+
+
 def test_training_losses_and_gradients_vs_f64_restatement():
     """Row a23 / config 5 parity: the 8 detectron2 losses and parameter gradients of one training step, HIP-backed graph
     (float32; DeformConv / ROIAlign forward + backward kernels) vs the float64 CPU restatement with autograd
     (oracle/detector_ref.losses - written independently of detnet/nn/training.py).  detectron2's random fg / bg subsampling is
     replaced on BOTH sides by "lowest indices" (training.first_choice), so the sampled anchors / proposals are comparable.
-    Tolerances: losses 1e-4 relative (north_star); gradients: every trainable tensor within 4e-3 of its largest entry, the median tensor
-    within 1e-3 - EXCEPT at most a quarter of the tensors (bottleneck tensors only), which may be off by up to 3e-2.  Why the exception (measured, round 5:
-    tools/train_grad_check.py REPEATS=6 in three processes, tools/diag_train_toggle.py): the float32 forward is not run-to-run identical (MIOpen's
-    split-K convolutions add with atomics: every res4 activation moves by ~7e-7 relative), and a DISCRETE decision inside a block's deformable
-    convolution - a ReLU input within that noise of zero, a bilinear sample within it of a pixel boundary - then falls on the other side than in
-    float64.  On the 10 x 14 res4 map of this test one pixel is 1 / 140 of every sum, so the four tensors of that block move together by a fixed
-    amount (res4.27: conv2_offset.weight 9e-3, conv2_offset.bias 8e-3, conv2_weight 6.6e-3, conv1.weight 4.4e-3 in about half of the runs, absent in
-    the others; res4.21 the same way in one run of six; res4.13.conv2_weight 3.7e-3 in every run, in the all-library graph too), while the block's
-    output gradient and every other block stay put.  Without a flip: worst tensor 2.6e-3, median 4.7e-4 (float32 summation order and float atomics
-    against a float64 reference through ~150 layers)."""
+    Tolerances: losses 1e-4 relative (north_star); gradients: every trainable tensor within 3e-3 of its largest entry, the median tensor within 1e-3 -
+    EXCEPT the tensors of blocks where a discrete decision of the float32 forward DEMONSTRABLY fell the other way than in float64 (both sides export
+    their ReLU masks and bilinear cells; _flipped_blocks compares them exactly) and of the blocks in front of such a block: _check_gradient_tiers.
+    Why flips exist (measured, rounds 5 / 6: tools/train_flip_check.py): the float32 forward is not run-to-run identical (library split-K kernels add
+    with atomics: every res4 activation moves by ~7e-7 relative); a ReLU input of res4.13's deformable conv sits within that noise of zero in every
+    run (its block: 3.7e-3), one of res4.27 in about half of the runs (8.9e-3; 2.3e-3 without it).  On the 10 x 14 res4 map of this test one pixel
+    is 1 / 140 of every sum."""
     import copy
     from oracle import detector_ref as R
     from waymo_2d_tracking_amd.detnet.nn.detectron2_det import Detectron2Det
@@ -131,8 +170,15 @@ def test_training_losses_and_gradients_vs_f64_restatement():
     ref, inter = R.losses(cpu, img, gt, cls, torch.float64, cfg['rpn_batch'], cfg['rpn_pos'], cfg['pre_nms'], cfg['post_nms'],
                           cfg['roi_batch'], cfg['roi_pos'], return_intermediates=True)
     sum(ref.values()).backward()
-    got = training.losses(m.model, img.cuda(), gt.cuda(), cls.cuda(), choose=training.first_choice, config=cfg,
-                          proposals=inter['proposals'].float().cuda())
+    from waymo_2d_tracking_amd.detnet.nn import cascade_rcnn
+    block_names = _block_names(m.model)
+    cascade_rcnn.DECISION_LOG = log = []
+    try:
+        got = training.losses(m.model, img.cuda(), gt.cuda(), cls.cuda(), choose=training.first_choice, config=cfg,
+                              proposals=inter['proposals'].float().cuda())
+    finally:
+        cascade_rcnn.DECISION_LOG = None
+    assert len(log) == len(block_names) == len(inter['blocks'])
     assert set(got) == set(ref) and len(ref) == 8
     for k in sorted(ref):
         assert abs(float(got[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (k, float(got[k]), float(ref[k]))
@@ -152,13 +198,8 @@ def test_training_losses_and_gradients_vs_f64_restatement():
             rel[n] = float((p.grad.double().cpu() - rp[n].grad.double()).abs().max()) / float(rp[n].grad.abs().max())
     for n in names:
         assert gp[n].grad is not None and rp[n].grad is not None and n in rel, n
-    # a flipped decision moves its own block by up to ~1e-2 and, through the gradient that flows on, the blocks upstream of it by a few 1e-3
-    # (seen: eleven consecutive res4 blocks at 6e-3 - 8e-3): bounded share of tensors above 4e-3, none above 3e-2, only bottleneck tensors among them
-    over = sorted((e, n) for n, e in rel.items() if e > 4e-3)
-    assert len(over) <= 0.25 * len(rel) and all(n.startswith('backbone.res') for _, n in over), over[-8:]
-    assert max(rel.values()) <= 3e-2, over[-3:]
-    ordered = sorted(rel.values())
-    assert ordered[len(ordered) // 2] <= 1e-3, ordered[len(ordered) // 2]
+    flipped = _flipped_blocks(block_names, [R.block_decisions(*t) for t in log], inter['blocks'])
+    _check_gradient_tiers(rel, block_names, flipped, tight=3e-3)
     assert len(rel) > 300
     # every trainable tensor: gradient direction agrees (cosine) - catches a wrong layout / missing term anywhere
     for n, p in gp.items():
@@ -184,29 +225,30 @@ def test_fused_training_epilogues_equal_the_plain_autograd_graph(monkeypatch):
     gt = torch.tensor([[20., 30., 120., 150.], [100., 40., 215., 155.], [5., 5., 60., 60.]]).cuda()
     cls = torch.tensor([0, 1, 3]).cuda()
     cfg = dict(pre_nms=300, post_nms=200, rpn_batch=64, rpn_pos=0.5, roi_batch=128, roi_pos=0.25)
+    from oracle import detector_ref as R
+    block_names = _block_names(m.model)
     out = {}
     for fused in (False, True):
         monkeypatch.setattr(cascade_rcnn, 'FUSED_TRAINING_EPILOGUES', fused)
         for p in m.model.parameters():
             p.grad = None
-        losses = training.losses(m.model, img, gt, cls, choose=training.first_choice, config=cfg)
+        cascade_rcnn.DECISION_LOG = log = []
+        try:
+            losses = training.losses(m.model, img, gt, cls, choose=training.first_choice, config=cfg)
+        finally:
+            cascade_rcnn.DECISION_LOG = None
         sum(losses.values()).backward()
         out[fused] = ({k: float(v) for k, v in losses.items()},
-                      {n: p.grad.clone() for n, p in m.model.named_parameters() if p.requires_grad and p.grad is not None})
-    (l0, g0), (l1, g1) = out[False], out[True]
+                      {n: p.grad.clone() for n, p in m.model.named_parameters() if p.requires_grad and p.grad is not None},
+                      [R.block_decisions(*t) for t in log])
+    (l0, g0, d0), (l1, g1, d1) = out[False], out[True]
     assert set(l0) == set(l1) and set(g0) == set(g1) and len(g0) > 300
     for k in l0:
         assert abs(l0[k] - l1[k]) <= 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
-    # gradients: float atomics move every tensor by up to ~2.5e-3 of its largest entry from run to run (tools/train_grad_check.py, "vs run 0");
-    # a discrete decision taken the other way (see the docstring of the float64 test above) moves the four tensors of its bottleneck block by up to
-    # 1e-2 and the blocks upstream of it by 6e-3 - 8e-3 (measured: 2 of 6 runs, eleven consecutive res4 blocks): a bounded share of the tensors may
-    # exceed 5e-3, none 3e-2, the median stays within 1e-3 (was: one 1e-2 bound for everything - 8.1e-3 seen)
+    # gradients: float atomics move every tensor by up to ~2.5e-3 of its largest entry from run to run (tools/train_grad_check.py, "vs run 0"); blocks
+    # whose discrete decisions differ between the two executions (exported and compared exactly) and the blocks in front of them get the wider tiers
     rel = {n: float((g0[n] - g1[n]).abs().max() / (g0[n].abs().max() + 1e-30)) for n in g0}
-    over = sorted((e, n) for n, e in rel.items() if e > 5e-3)
-    assert len(over) <= 0.25 * len(rel) and all(n.startswith('backbone.res') for _, n in over), over[-8:]
-    assert max(rel.values()) <= 3e-2, over[-3:]
-    ordered = sorted(rel.values())
-    assert ordered[len(ordered) // 2] <= 1e-3, ordered[len(ordered) // 2]
+    _check_gradient_tiers(rel, block_names, _flipped_blocks(block_names, d0, d1), tight=4e-3, max_flipped=8)
 
 
 def test_training_step_full_size_properties():

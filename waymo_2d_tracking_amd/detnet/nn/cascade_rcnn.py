@@ -51,6 +51,11 @@ SPLIT_PARTS = set(os.environ.get('WD_SPLIT_PARTS', 'conv1x1,conv3x3,head,fc,offs
 OFFSET_SPLIT_MIN_ROWS = int(os.environ.get('WD_OFFSET_SPLIT_MIN_ROWS', '30000'))
 
 
+# Parity tests set this to a list: every Bottleneck.forward then appends (conv1 output, offsets or None, conv2 output, block output, stride) - the
+# post-ReLU maps and sampling offsets from which oracle.detector_ref.block_decisions derives the block's discrete decisions (ReLU masks, bilinear cells).
+DECISION_LOG = None
+
+
 def _split_ok(cin, cout, part='conv1x1'):
     return SPLIT_GEMM and part in SPLIT_PARTS and cin % 64 == 0 and cout % 32 == 0
 
@@ -233,6 +238,9 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)
         out = self.conv1(x, relu=True)
+        rec = DECISION_LOG
+        if rec is not None:                              # parity tests: the block's discrete decisions (ReLU masks, bilinear cells), see DECISION_LOG
+            out1, offset = out, None
         if self.deform and torch.is_grad_enabled():      # training: autograd Function around the HIP fwd / bwd kernels
             offset = self.conv2_offset(out)
             if FUSED_TRAINING_EPILOGUES and not (self.conv2_scale.requires_grad or self.conv2_bias.requires_grad):
@@ -258,7 +266,12 @@ class Bottleneck(nn.Module):
         else:
             out = ops.deform_conv3x3(out, None, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale,
                                      self.conv2_bias, relu=True)
-        return self.conv3(out, relu=True, residual=sc)
+        if rec is None:
+            return self.conv3(out, relu=True, residual=sc)
+        out3 = self.conv3(out, relu=True, residual=sc)
+        # (clones: at inference / in frozen blocks the block output lands in the residual's buffer, which the next block overwrites)
+        rec.append((out1.detach().clone(), None if offset is None else offset.detach().clone(), out.detach().clone(), out3.detach().clone(), self.stride))
+        return out3
 
 
 class ResNeXt152FPN(nn.Module):
