@@ -47,8 +47,9 @@ def parse_args():
                     help='e2e: run the per-chunk birth-count exchange + row-block gather to rank 0 also with one rank '
                          '(always on when N > 1 or WT_FORCE_DIST=1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--inflight', type=int, default=1,
-                    help='e2e/detect: frames in flight (hipGraph lanes on separate streams); > 1 is refused unless WT_EXPERIMENT=1 (deadlocks at 1920x1280)')
+    ap.add_argument('--inflight', type=int, default=2,
+                    help='e2e/detect: frames in flight (hipGraph lanes on separate streams, default 2: the tails and ramps of one frame run under the '
+                         "other frame's kernels; the all-library WD_SPLIT_GEMM=0 graph must use 1: its library kernels deadlock with two lanes)")
     ap.add_argument('--auto-contrast', action='store_true', help='e2e/detect: ImageOps.autocontrast on every frame (the --auto-contrast=1 of the '
                     "reference's documented TTA run, README.md:37)")
     ap.add_argument('--from-jpeg', action='store_true', help='e2e/detect: the frames enter as JPEG bytes and are decoded on the GPU inside the step '
@@ -61,10 +62,11 @@ def parse_args():
 
 
 def check_flags(args):
-    """--inflight > 1 deadlocks at 1920x1280 (two hipGraph lanes whose library kernels spin-wait on each other): an experiment, refused unless
-    WT_EXPERIMENT=1 says the caller knows."""
-    if args.inflight > 1 and os.environ.get('WT_EXPERIMENT') != '1':
-        raise SystemExit('bench.py: --inflight %d is an experiment that deadlocks at full size; set WT_EXPERIMENT=1 to run it anyway' % args.inflight)
+    """Two hipGraph lanes of the ALL-LIBRARY graph (WD_SPLIT_GEMM=0) deadlocked at 1920x1280 in round 2 (library kernels that spin-wait on partner
+    workgroups): that combination is refused unless WT_EXPERIMENT=1 says the caller knows.  The default graph (own kernels) runs two lanes."""
+    if args.inflight > 1 and os.environ.get('WD_SPLIT_GEMM') == '0' and os.environ.get('WT_EXPERIMENT') != '1':
+        raise SystemExit('bench.py: --inflight %d with WD_SPLIT_GEMM=0 (all-library graph) deadlocks at full size; use --inflight 1 or set WT_EXPERIMENT=1'
+                         % args.inflight)
 
 
 def launch_if_needed(args):

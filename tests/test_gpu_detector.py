@@ -431,11 +431,18 @@ def test_inference_cli_on_image_folder(tmp_path):
     # 1e-4 px of a rounding boundary or two scores within 1e-7 of each other may come out the other way: rows are matched, not compared by position)
     assert abs(len(rows) - len(ref_rows)) <= 1
     assert [r['image_id'] for r in rows[:1]] == [r['image_id'] for r in ref_rows[:1]]
-    matched = 0
+    # wire rows carry INTEGER boxes and 5-decimal scores: a float coordinate on a rounding boundary moves its integer by exactly 1, a score by exactly
+    # 1e-5 - nothing in between exists.  Bounded (round 6): a row matches when every coordinate is within 1 and the score within one unit of the 5th
+    # decimal; over ALL matched rows at most 3 coordinates may differ at all (expected ~0.2 of ~1200 with 1e-4 px of float32 noise)
+    matched, coord_diffs = 0, 0
     for r in rows:
-        matched += any(q['image_id'] == r['image_id'] and q['category_id'] == r['category_id'] and
-                       max(abs(a - b) for a, b in zip(q['bbox'], r['bbox'])) <= 1 and abs(q['score'] - r['score']) <= 2e-5 for q in ref_rows)
+        cands = [q for q in ref_rows if q['image_id'] == r['image_id'] and q['category_id'] == r['category_id'] and
+                 max(abs(a - b) for a, b in zip(q['bbox'], r['bbox'])) <= 1 and abs(q['score'] - r['score']) <= 1.01e-5]
+        if cands:
+            matched += 1
+            coord_diffs += min(sum(a != b for a, b in zip(q['bbox'], r['bbox'])) for q in cands)
     assert matched >= len(rows) - 1, (matched, len(rows))
+    assert coord_diffs <= 3, coord_diffs
     assert list(dict.fromkeys(r['image_id'] for r in rows)) == list(dict.fromkeys(r['image_id'] for r in ref_rows))
     # -o wrote the store; --resume on a store that holds two of the four images detects only the others and merges
     store = Predictions.open(tmp_path / 'o')

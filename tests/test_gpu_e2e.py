@@ -289,6 +289,40 @@ def test_two_pipelines_in_flight_on_different_streams_equal_serial_runs():
         torch.cuda.tunable.enable(saved[2])
 
 
+@pytest.mark.parametrize('size,steps', [((256, 384), 3), ((1280, 1920), 2)])
+def test_two_frames_in_flight_fill_the_same_slots_as_one(oracle, size, steps):
+    """Round 6: two hipGraph lanes on separate streams (bench.py --inflight 2, the default) against one lane: the detector is deterministic in this mode
+    (own kernels + deterministic library picks), so every detection slot and every tracker row must be IDENTICAL - at a small size and at 1920x1280,
+    where two lanes of the round-2 (library) graph deadlocked; the tracker rows also equal the oracle's replay."""
+    import torch
+    from waymo_2d_tracking_amd.bench_e2e import DetectTrackPipeline, check_against
+    saved = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic, torch.cuda.tunable.is_enabled())
+    kw = dict(n_cameras=2, frames_per_camera=2, height=size[0], width=size[1], segment_frames=8, distinct_times=4, use_graph=True, deterministic=True,
+              defer_tracking=True)
+    try:
+        snaps = []
+        for lanes in (1, 2):
+            p = DetectTrackPipeline(seed=5, n_inflight=lanes, **kw)
+            for _ in range(steps):
+                p.step(True)
+            p.flush()
+            torch.cuda.synchronize()
+            rep = check_against(p, oracle.track_streams)
+            assert rep['ok'], rep
+            snap = [p.category[:steps].clone(), p.xywhs[:steps].clone()]
+            for c in range(steps):
+                k = int(p.chunk_counts[c, 0])
+                snap += [p.out_bbox[c][:k].clone(), p.out_id[c][:k].clone()]
+            snaps.append(snap)
+            del p
+        assert int((snaps[0][0] != 0).sum()) > 0
+        for a, b in zip(*snaps):
+            assert a.shape == b.shape and torch.equal(a, b)
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = saved[0], saved[1]
+        torch.cuda.tunable.enable(saved[2])
+
+
 def test_pipeline_with_frames_entering_as_jpeg(oracle):
     """SURVEY 8f rank 3 inside the timed pipeline: the frames of step s + 1 are decoded on the GPU by loader threads while the
     detector works on step s.  Every frame slot holds exactly PIL's decode of its file when its step reads it (checked after

@@ -104,6 +104,21 @@ def make_victims():
     ow = ops.tap_gemm_weight((torch.randn((18, 1024, 3, 3), generator=g) / 96).to(dev))
     obias = torch.randn(18, generator=g).to(dev)
     v['offset_conv'] = lambda: ops.conv3x3_few(ox, ow, obias, 18)
+    # what is left on the libraries in the frame (MIOpen / hipBLASLt through torch): stem 7x7, stride-2 offset conv, RPN predictors, max pool, softmax
+    import torch.nn.functional as F
+    xs = cl(torch.randn((1, 3, 640, 960), generator=g))
+    ws = cl((torch.randn((64, 3, 7, 7), generator=g) / 12).to(dev))
+    v['lib_stem_conv7x7_s2'] = lambda: F.conv2d(xs, ws, None, 2, 3)
+    xo = cl(torch.randn((1, 1024, 40, 60), generator=g) * 0.5)
+    wo = cl((torch.randn((18, 1024, 3, 3), generator=g) / 96).to(dev))
+    v['lib_offset_conv3x3_s2'] = lambda: F.conv2d(xo, wo, None, 2, 1)
+    xr = torch.randn(76800, 256, generator=g).to(dev)
+    wr, br = (torch.randn(12, 256, generator=g) / 16).to(dev), torch.randn(12, generator=g).to(dev)
+    v['lib_rpn_predictor_gemm'] = lambda: torch.addmm(br, xr, wr.t())
+    xm = cl(torch.randn((1, 64, 320, 480), generator=g))
+    v['lib_max_pool'] = lambda: F.max_pool2d(xm, 3, 2, 1)
+    lg = torch.randn(1000, 5, generator=g).to(dev)
+    v['lib_softmax'] = lambda: torch.softmax(lg, 1)
     # SORT (sort_streams_kernel) and soft-NMS ensemble through their host entry points
     from waymo_2d_tracking_amd import synthetic as syn
     from waymo_2d_tracking_amd.tracking import utils as T

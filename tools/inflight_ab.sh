@@ -1,0 +1,31 @@
+#!/bin/bash
+# GPU box: frames in flight (hipGraph lanes on separate streams) A/B for the bench stages.  usage: tools/inflight_ab.sh name bench-args... (repeatable via ;)
+cd "$(dirname "$0")/.."
+export WT_EXPERIMENT=1
+O=gpurun_out/r06_inflight
+mkdir -p $O
+run() {
+  name=$1; shift
+  timeout 500 python bench.py "$@" --no-cpu-baseline > $O/$name.json 2> $O/$name.err
+  echo "$name rc=$?"
+  python - "$O/$name.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print('    %.2f %s  %.1f ms/step  verified %s' % (d['value'], d['unit'], d['ms_per_step'], (d.get('verified') or {}).get('ok')))
+except Exception as e:
+    print('    no line', e)
+PY
+}
+case "$1" in
+  sweep)
+    run e2e_if3 --inflight 3 --steps 10 --warmup 3
+    run e2e_if4 --inflight 4 --steps 10 --warmup 3
+    run detect_if2 --stage detect --inflight 2 --steps 10 --warmup 3
+    run detect_if1 --stage detect --inflight 1 --steps 10 --warmup 3
+    run tta_if2 --stage detect --tta x1.5,hflip --auto-contrast --inflight 2 --steps 6 --warmup 2
+    run tta_if1 --stage detect --tta x1.5,hflip --auto-contrast --inflight 1 --steps 6 --warmup 2
+    run jpeg_if2 --from-jpeg --inflight 2 --steps 10 --warmup 3
+    ;;
+  *) run "$@" ;;
+esac

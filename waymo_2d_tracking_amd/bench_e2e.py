@@ -134,10 +134,14 @@ class DetectTrackPipeline(object):
     def _capture(self):
         """Per lane: warm up eagerly on the lane's stream (MIOpen / TunableOp / hipBLASLt pick their kernels, per-stream scratch
         gets allocated), then capture the whole per-frame detector as one hipGraph on that stream.  Every lane owns its input /
-        output / intermediate buffers, so the graphs of consecutive frames could be in flight at the same time (the serial tails
-        of one frame under the other frame's GEMMs).  n_inflight = 1 is the default and the only supported setting at full
-        size: two 1920x1280 detector graphs in flight DEADLOCK on MI355X (measured, round 2) - library kernels that spin on
-        partner workgroups need all of them resident, which two chip-filling kernels on different streams do not guarantee."""
+        output / intermediate buffers, so the graphs of consecutive frames are in flight at the same time: the one-workgroup tails
+        of one frame (NMS sweep, candidate sorts, top-k stages), the 16 CUs a 240-tile GEMM leaves idle and every kernel's ramp up /
+        down run under the other frame's kernels.  Round 6: with 90 % of the frame on own kernels two lanes run at full size
+        (1920x1280: 38.9 -> 43.4 frames/s on one box, 40.8 -> 44.6 detector alone; three lanes 44.4, four 43.6: tools/inflight_ab.sh,
+        profiles/r06_inflight_ab.txt); in round 2, with 79 % library kernels, the same setting DEADLOCKED (library kernels that spin on
+        partner workgroups need all of them resident) - the all-library exact-f32 graph (WD_SPLIT_GEMM=0) therefore keeps ONE lane.
+        Every product kernel was checked as a co-resident victim of the split-operand kernel on another stream
+        (profiles/r06_costream_victim_side.txt)."""
         saved, ops.EVENT_LOG = ops.EVENT_LOG, None          # no event records inside a capture
         torch.cuda.synchronize()
         self._lanes = []
@@ -239,9 +243,22 @@ class DetectTrackPipeline(object):
             self._capture()
         lane = self._lanes[self._frame_no % self.n_inflight]
         self._frame_no += 1
+        others = [l for l in self._lanes if l is not lane]
+        if eager and others:
+            # the instrumented frame runs ALONE on the chip (its HIP events time kernels, not kernels sharing CUs with another frame's): it starts
+            # behind everything the other lanes have queued and they resume behind it
+            for l in others:
+                ev = torch.cuda.Event()
+                ev.record(l['stream'])
+                lane['stream'].wait_event(ev)
         with torch.cuda.stream(lane['stream']):
             if eager:
                 xywhs, cat, cnt = self._detect_core(img)
+                if others:
+                    ev = torch.cuda.Event()
+                    ev.record(lane['stream'])
+                    for l in others:
+                        l['stream'].wait_event(ev)
                 if self._pending_track is not None:              # (an instrumented frame is never the first of a step)
                     self.flush()
             else:
@@ -499,12 +516,14 @@ def _pmc_traffic(tag):
     return None
 
 
-def exact_f32_line(args, rank, track, fps, steps):
-    """The all-exact-f32 configuration (every convolution on the f32 library / f32-MFMA path, WD_SPLIT_GEMM=0) timed in the SAME invocation on
-    a second pipeline: the secondary line the round-4 review asked to carry next to the split-operand headline."""
+def exact_f32_line(args, rank, track, fps, steps, exact=True):
+    """Secondary lines timed in the SAME invocation on a second pipeline.  exact=True: the all-exact-f32 configuration (every convolution on the f32
+    library / f32-MFMA path, WD_SPLIT_GEMM=0; ONE frame in flight - its library kernels deadlock with two lanes), the line the round-4 review asked to
+    carry next to the split-operand headline.  exact=False (round 6): the headline's own graph with ONE frame in flight, i.e. without the overlap of
+    consecutive frames."""
     import time
     from .detnet.nn import cascade_rcnn
-    cascade_rcnn.SPLIT_GEMM = False
+    cascade_rcnn.SPLIT_GEMM = not exact
     try:
         pipe = DetectTrackPipeline(5, fps, seed=rank, tta=getattr(args, 'tta', '') or '', use_graph=not getattr(args, 'no_graph', False),
                                    defer_tracking=track and not getattr(args, 'no_defer_track', False), auto_contrast=getattr(args, 'auto_contrast', False))
@@ -520,7 +539,8 @@ def exact_f32_line(args, rank, track, fps, steps):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out = dict(value=pipe.n_frames * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, steps=steps, warmup=1,
-                   note='same pipeline with WD_SPLIT_GEMM=0: 1x1 convolutions on hipBLASLt f32, dense 3x3 on MIOpen f32')
+                   note=('same pipeline with WD_SPLIT_GEMM=0: 1x1 convolutions on hipBLASLt f32, dense 3x3 on MIOpen f32; one frame in flight' if exact else
+                         'same graph, one frame in flight (no overlap of consecutive frames)'))
         del pipe
     finally:
         cascade_rcnn.SPLIT_GEMM = True
@@ -637,6 +657,11 @@ def run(args, world, rank, timed_steps):
         res['extra']['split_gemm'] = True
         if world == 1 and os.environ.get('WT_BENCH_NO_EXACT') != '1':
             res['extra']['exact_f32'] = exact_f32_line(args, rank, track, fps, min(steps, 3))
+            if pipe.n_inflight > 1:
+                res['extra']['one_frame_in_flight'] = exact_f32_line(args, rank, track, fps, min(steps, 3), exact=False)
+    res['extra']['frames_in_flight'] = pipe.n_inflight
+    if pipe.n_inflight > 1:
+        res['workload'] += ('; %d frames in flight (hipGraph lanes on separate streams; the instrumented frame of a step runs alone)' % pipe.n_inflight)
     if pipe.jpeg is not None:
         import io
         from PIL import Image
