@@ -814,7 +814,9 @@ int experiment_knob(const char* name) {
 // Tile height (32 MT rows) and K slices for a shape.  Cost model in microseconds from the measured ring kernel (MI355X, profiles/r05_split_*):
 // a K step of 32 costs ~0.52 us per 32-row block of the tile, prologue + epilogue ~(2 + MT) us per workgroup, 256 workgroups run at once;
 // a split adds the reduce launch (3 us + the partial tiles through HBM at ~4 TB/s).  Shapes with few tiles (FPN p5 / p6, the box-head FC)
-// fill the chip through K slices; large ones pick the tile height with the fewest idle CU-rounds.
+// fill the chip through K slices; large ones pick the tile height with the fewest idle CU-rounds.  (Round 6, two frames in flight: pricing a launch by
+// its work alone - "the other frame fills the CUs a partial round leaves idle" - picks smaller tiles / fewer slices and LOSES 7 %: 41.3 -> 38.5 frames/s,
+// two alternating runs on one box; the rounds stay in the model.)
 struct Plan { int mt, splitk; };
 
 // Tile heights of 2 and 3 row blocks (64 / 96 rows) are NOT offered.  While waves that issue back-to-back v_mfma_f32_32x32x16_bf16 share a SIMD
