@@ -1,9 +1,11 @@
 #!/bin/bash
-# steady-state kernel breakdown of one frame of the default bench (kernel trace, last frames only)
+# steady-state kernel breakdown of one frame of the bench (kernel trace, last frames only).  INFLIGHT=1 (default here): the anatomy of ONE frame, kernel
+# durations not stretched by a second frame sharing the chip; INFLIGHT=2: the default bench - kernel time per frame then sums OVERLAPPING kernels
+# (kernel time / wall = the average number of kernels in flight)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 export WT_BENCH_NO_EXACT=1   # the trace must end with the headline pipeline, not the exact-f32 secondary run
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_e2e -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/e2e.json 2>/tmp/e2e.log
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_e2e -- python3 $R/bench.py --inflight ${INFLIGHT:-1} --steps 3 --warmup 2 --no-cpu-baseline > /tmp/e2e.json 2>/tmp/e2e.log
 python3 - "$(find /tmp/prof_e2e -name '*kernel_trace.csv' | head -1)" $R/gpurun_out/e2e_frame_sequence.txt > $R/gpurun_out/e2e_steady.txt <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))

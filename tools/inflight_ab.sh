@@ -27,5 +27,12 @@ case "$1" in
     run tta_if1 --stage detect --tta x1.5,hflip --auto-contrast --inflight 1 --steps 6 --warmup 2
     run jpeg_if2 --from-jpeg --inflight 2 --steps 10 --warmup 3
     ;;
+  lanes)
+    run e2e_l2_a --inflight 2 --steps 10 --warmup 3
+    run e2e_l3_a --inflight 3 --steps 10 --warmup 3
+    run e2e_l2_b --inflight 2 --steps 10 --warmup 3
+    run e2e_l3_b --inflight 3 --steps 10 --warmup 3
+    run e2e_l1 --inflight 1 --steps 10 --warmup 3
+    ;;
   *) run "$@" ;;
 esac

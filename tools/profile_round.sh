@@ -8,7 +8,12 @@ cd /tmp && export TMPDIR=/tmp
 WT_BENCH_NO_EXACT=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /tmp/prof_stats.log
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/e2e_kernel_stats.csv
 cd $R
-bash tools/e2e_profile.sh > /dev/null 2>&1; cp gpurun_out/e2e_steady.txt $OUT/e2e_steady_per_frame.txt
+cd /tmp
+WT_BENCH_NO_EXACT=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python3 $R/bench.py --inflight 1 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof_one_lane.json 2> /tmp/prof_stats1.log
+cp $(find /tmp/prof_stats1 -name "*kernel_stats.csv" | head -1) $OUT/e2e_kernel_stats_one_lane.csv
+cd $R
+INFLIGHT=1 bash tools/e2e_profile.sh > /dev/null 2>&1; cp gpurun_out/e2e_steady.txt $OUT/e2e_steady_per_frame.txt; cp gpurun_out/e2e_frame_sequence.txt $OUT/e2e_frame_sequence.txt
+INFLIGHT=2 bash tools/e2e_profile.sh > /dev/null 2>&1; cp gpurun_out/e2e_steady.txt $OUT/e2e_steady_per_frame_two_lanes.txt
 bash tools/train_profile.sh > /dev/null 2>&1; cp gpurun_out/train_steady.txt $OUT/train_steady_per_step.txt
 python3 bench.py --steps 5 --warmup 2 > $OUT/e2e_bench_line.json 2>/dev/null
 python3 bench.py --stage train --steps 5 --warmup 3 --no-cpu-baseline > $OUT/train_bench_line.json 2>/dev/null
@@ -26,7 +31,6 @@ bash tools/pmc_traffic.sh > /dev/null 2>&1; cp gpurun_out/prof_e2e/pmc_traffic.j
 bash tools/jpeg_profile.sh 20 > /dev/null 2>&1; cp gpurun_out/jpeg/per_image.txt $OUT/jpeg_per_kernel.txt; cp gpurun_out/jpeg/bench.txt $OUT/jpeg_single_call_vs_pil.txt
 # round 5: the split-operand kernel - counters, compile-time ablations, per-shape time / error table, whole-detector drift
 bash tools/pmc_split.sh 9600 1024 1024 1 $OUT/split_pmc.txt > /dev/null 2>&1
-bash tools/split_ablation.sh "9600 1024 1024" > $OUT/split_ablation.txt 2>&1
 python3 tools/gemm_split_bench.py --json $OUT/split_gemm_bench.json > /dev/null 2>&1
 python3 tools/split_box_drift.py --out $OUT/split_box_drift.txt > /dev/null 2>&1
 for f in $OUT/*_bench_line.json; do echo $f; tail -1 $f | cut -c1-170; done

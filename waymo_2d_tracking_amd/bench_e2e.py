@@ -503,7 +503,7 @@ def _pmc_traffic(tag):
     collected with tools/pmc_traffic.sh - counters cannot be read from inside the timed run); None if not recorded."""
     import json
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-    for fname in ('r05_e2e_pmc_traffic.json', 'r04_e2e_pmc_traffic.json', 'r03_e2e_pmc_traffic.json', 'r02_e2e_pmc_traffic.json', 'r01_e2e_pmc_traffic.json'):
+    for fname in ('r06_e2e_pmc_traffic.json', 'r05_e2e_pmc_traffic.json', 'r04_e2e_pmc_traffic.json', 'r03_e2e_pmc_traffic.json', 'r02_e2e_pmc_traffic.json', 'r01_e2e_pmc_traffic.json'):
         try:
             rec = json.load(open(os.path.join(root, fname)))
         except (OSError, ValueError):
@@ -640,8 +640,10 @@ def run(args, world, rank, timed_steps):
         roofline['split_gemm'] = split_roof
     if roofline is not None:
         roofline['timing_note'] = ('avg_us: HIP events on the launch stream around every launch of the LAST frame of each timed step, which runs eagerly '
-                                   '(the other frames replay the captured hipGraph of the same launches and share the chip with the SORT kernel of the '
-                                   'previous chunk); rocprofv3 --kernel-trace of the same command agrees (profiles/)')
+                                   'and ALONE on the chip (the other frames replay the captured hipGraph of the same launches, two frames in flight, and share '
+                                   'the chip with each other and with the SORT kernel of the previous chunk: a kernel duration taken there would include time '
+                                   'spent sharing CUs); rocprofv3 --kernel-trace --stats of the same command with --inflight 1 agrees '
+                                   '(profiles/r06_e2e_kernel_stats_one_lane.csv; the two-lane trace is profiles/r06_e2e_kernel_stats.csv)')
     from .detnet.nn import cascade_rcnn
     split_on = cascade_rcnn.SPLIT_GEMM
     res = dict(value=frames * world * steps / dt, unit='frames/s', ms_per_step=1e3 * dt / steps, dtype='f32',
