@@ -81,3 +81,17 @@ def test_split_pack_descriptor_layout_matches_the_header():
     assert [n for n, _ in fields] == list(dt.names) == list(ops._PACK_DESC_FIELDS)
     for name, _ in fields:
         assert dt.fields[name][1] == getattr(Desc, name).offset, name
+
+
+def test_split_io_struct_layout_matches_the_header():
+    """ops._SplitIO (handed to wd_gemm_split_io) == struct WdSplitIO of include/waymodet.h: same field names in the same order, eight 8-byte fields."""
+    import ctypes as C
+    import re
+    from waymo_2d_tracking_amd.detnet.nn import ops
+    text = open(os.path.join(ROOT, 'include', 'waymodet.h')).read()
+    body = re.search(r'typedef struct WdSplitIO \{(.*?)\} WdSplitIO;', text, re.S).group(1)
+    names = [d.replace('*', ' ').split()[-1] for d in body.split(';') if d.strip()]
+    assert names == [f[0] for f in ops._SplitIO._fields_]
+    assert C.sizeof(ops._SplitIO) == 64
+    for (name, ctype), decl in zip(ops._SplitIO._fields_, [d.strip() for d in body.split(';') if d.strip()]):
+        assert (ctype is C.c_long) == decl.startswith('long'), (name, decl)
