@@ -386,6 +386,48 @@ def _random_model_file(tmp_path, seed=0):
     return str(path)
 
 
+def _rows_match(rows, ref_rows):
+    """Wire rows (integer boxes, 5-decimal scores) of two float32 detector runs: every row has a partner within one unit per coordinate / one unit of the 5th
+    decimal, at most 3 coordinates differ at all (see test_inference_cli_on_image_folder)."""
+    assert abs(len(rows) - len(ref_rows)) <= 1
+    matched, coord_diffs = 0, 0
+    for r in rows:
+        cands = [q for q in ref_rows if q['image_id'] == r['image_id'] and q['category_id'] == r['category_id'] and
+                 max(abs(a - b) for a, b in zip(q['bbox'], r['bbox'])) <= 1 and abs(q['score'] - r['score']) <= 1.01e-5]
+        if cands:
+            matched += 1
+            coord_diffs += min(sum(a != b for a, b in zip(q['bbox'], r['bbox'])) for q in cands)
+    assert matched >= len(rows) - 1, (matched, len(rows))
+    assert coord_diffs <= 3, coord_diffs
+    assert list(dict.fromkeys(r['image_id'] for r in rows)) == list(dict.fromkeys(r['image_id'] for r in ref_rows))
+
+
+def test_inference_cli_with_frames_in_flight_equals_the_per_image_loop(tmp_path):
+    """Round 6: inference.py with `--inflight 2` (default: every image size captured once per lane as a hipGraph, two passes in flight, results collected
+    one image behind - nn.GraphLanePredictor) writes the same detection JSON as `--inflight 0` (one eager Detectron2Det.predict per image): two image
+    sizes (the front / side cameras), with and without the folded TTA plan, more images than lanes, an odd count."""
+    import json
+    from PIL import Image
+    from waymo_2d_tracking_amd.detnet import inference as I
+    rng = np.random.default_rng(1)
+    root = tmp_path / 'images'
+    for i in range(7):
+        cam = ('FRONT', 'SIDE_LEFT')[i % 2]
+        d = root / 'seg' / str(100 + i)
+        d.mkdir(parents=True, exist_ok=True)
+        arr = rng.integers(30, 200, ((96, 64)[i % 2], 160, 3), dtype=np.uint8)
+        Image.fromarray(arr).save(d / (cam + '.jpg'), quality=92)
+    model = _random_model_file(tmp_path)
+    for tta in ([], ['--tta', 'x1.5,hflip']):
+        out = {}
+        for lanes in (0, 2):
+            path = tmp_path / ('sub%d.json' % lanes)
+            I.main(['-m', model, '-i', str(root), '--export', str(path), '--batch-size=1', '--inflight', str(lanes)] + tta)
+            out[lanes] = json.load(open(path))
+        assert len(out[0]) > 0
+        _rows_match(out[2], out[0])
+
+
 def test_inference_cli_on_image_folder(tmp_path):
     """inference.py drop-in: image folder -> detection JSON (coco.py:229-252 rows) == predict + load_prediction; -o writes the
     prediction store, --resume skips the tested samples and merges, --auto-contrast changes the input like PIL does."""

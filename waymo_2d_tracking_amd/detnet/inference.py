@@ -51,6 +51,9 @@ def add_test_argument(parser):
     parser.add_argument("--batch-size", type=int, default=0)
     parser.add_argument("--resize", type=str)
     parser.add_argument("--max-image-size", type=int)
+    parser.add_argument("--inflight", type=int, default=2,
+                        help="(extension) detector passes in flight: each image size is captured once per lane as a hipGraph and replayed on its own "
+                             "stream, results are collected one image behind; 0 = one eager call per image")
     parser.add_argument("--decoder", type=str, default='gpu', choices=('gpu', 'pil'),
                         help="JPEG decoding: 'gpu' = HIP decoder (bit-exact with PIL), 'pil' = host decode like the reference")
     parser.add_argument("--auto-contrast", type=arg2bool)
@@ -90,6 +93,25 @@ class PredictModel(torch.nn.Module):
 
     def forward(self, sample):
         return [self.post_process(d) for d in self.model.predict(sample)]
+
+    # ---- round 6: the same results for a STREAM of images with `lanes` detector passes in flight (captured hipGraphs, nn.GraphLanePredictor) ----
+    def stream(self, lanes=2):
+        """A (submit, collect) pair or None when this model / TTA plan has no static-shape pass (the loop then calls forward() per image)."""
+        from .nn.tta import TTA, undo_plan
+        if isinstance(self.model, TTA):
+            gl, plan = self.model.graph_lanes(lanes), self.model.plan
+        elif hasattr(self.model, 'predict_padded') and not getattr(self.model, 'tta_min_sizes', None):
+            from .nn.detectron2_det import GraphLanePredictor
+            gl, plan = GraphLanePredictor(self.model, lanes=lanes), []
+        else:
+            gl = None
+        if gl is None:
+            return None
+
+        def collect(ticket):
+            det = [[b.copy() for b in gl.collect(ticket)]]
+            return self.post_process(undo_plan(det, plan)[0])
+        return gl.submit, collect
 
     def post_process(self, detections):
         max_bbox = self.detect_args.get('max_bbox', 0)
@@ -293,11 +315,24 @@ def run_rank(args, world, rank):
     index = {k: i for i, k in enumerate(image_ids)}
     with torch.no_grad():
         loader = ImageLoader(images[lo:hi], args.resize, args.max_image_size, auto_contrast=args.auto_contrast, decoder=args.decoder)
+        # round 6: `--inflight` detector passes in flight, each a captured hipGraph per image size (the Waymo cameras have two); results are collected
+        # one image behind.  --inflight 0: the per-image eager call of the earlier rounds (and the only form for TTA plans / models without a
+        # static-shape pass)
+        lanes = predict.stream(args.inflight) if args.inflight > 0 else None
+        pending = []
         for image_id, img, (w, h) in loader:
             if args.auto_contrast and not loader.auto_contrast_in_loader:
                 img = autocontrast_(img)
-            store[image_id] = predict(img.unsqueeze(0))[0]            # uint8 HWC -> fused pre-processing kernel
             sizes[index[image_id]] = (w, h)
+            if lanes is None:
+                store[image_id] = predict(img.unsqueeze(0))[0]        # uint8 HWC -> fused pre-processing kernel
+                continue
+            pending.append((image_id, lanes[0](img)))
+            if len(pending) > args.inflight:
+                k, t = pending.pop(0)
+                store[k] = lanes[1](t)
+        for k, t in pending:
+            store[k] = lanes[1](t)
     cols, tested = store.shard_columns()
     allc = D.gather_columns_rank0(cols)                               # the one exchange: result rows -> rank 0
     meta = D.gather_columns_rank0(dict(image=np.nonzero(tested)[0].astype(np.int32), size=sizes[tested]))

@@ -193,6 +193,93 @@ class Detectron2Det(Module):
         return output[0] if single else output
 
 
+class GraphLanePredictor:
+    """Detectron2Det.predict for a STREAM of equally sized images (inference.py's loop, detnet/inference.py:151 of the reference), round 6: the detector
+    pass of an image size is captured once per lane as a hipGraph with static shapes (predict_padded + the box normalisation of predict(), no host
+    synchronisation) and `lanes` frames are in flight on separate streams - the serial tails of one frame run under the other frame's kernels
+    (profiles/r06_inflight_ab.txt).  submit() enqueues an image and returns a ticket; collect(ticket) waits for THAT image only and returns what
+    predict() returns for one image: per class an (n, 5) float32 array [score, cx, cy, w, h], normalised in the transformed image.
+    One set of lanes per (height, width): the Waymo cameras have two sizes."""
+
+    MAX_SIZES = 4          # distinct image sizes that get their own captured lanes (graph pools are a few GB each at 1920x1280); further sizes run eagerly
+
+    def __init__(self, det, scale=1.0, hflip=False, vflip=False, lanes=2):
+        self.det, self.pre = det, (float(scale), bool(hflip), bool(vflip))
+        self.n_lanes = max(1, int(lanes))
+        self._sets = {}
+        self._turn = 0
+
+    def _lane_set(self, h, w, dev):
+        key = (h, w, dev)
+        if key in self._sets:
+            return self._sets[key]
+        det, lanes = self.det, []
+        saved, ops.EVENT_LOG = ops.EVENT_LOG, None
+        torch.cuda.synchronize(dev)
+        for _ in range(self.n_lanes):
+            lane = dict(stream=torch.cuda.Stream(device=dev), gin=torch.zeros((1, h, w, 3), dtype=torch.uint8, device=dev), ticket=None)
+
+            def core(lane=lane):
+                boxes, scores, classes, cnt = det.predict_padded(lane['gin'], *self.pre)
+                ho, wo = det.last_input_size
+                bx = boxes.clone()                          # Detectron2Det.predict (:119-131): the same float32 operations in the same order
+                bx[:, 0::2] *= 1.0 / wo
+                bx[:, 1::2] *= 1.0 / ho
+                center = (bx[:, :2] + bx[:, 2:]) / 2
+                wh = bx[:, 2:4] - bx[:, 0:2]
+                return torch.cat((scores.unsqueeze(1), center, wh), dim=1), classes, cnt
+
+            with torch.cuda.stream(lane['stream']), torch.no_grad():
+                for _ in range(2):                          # library kernel selection, per-stream scratch
+                    core()
+            lane['stream'].synchronize()
+            lane['graph'] = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(lane['graph'], stream=lane['stream'], capture_error_mode='thread_local'):
+                lane['out'] = core()
+            lane['host'] = tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in lane['out'])
+            lanes.append(lane)
+        torch.cuda.synchronize(dev)
+        ops.EVENT_LOG = saved
+        self._sets[key] = lanes
+        return lanes
+
+    def submit(self, img):
+        """img: (1, H, W, 3) or (H, W, 3) uint8 RGB on the device.  Returns a ticket for collect()."""
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        assert img.dtype == torch.uint8 and img.is_cuda and img.shape[0] == 1 and img.shape[3] == 3, 'GraphLanePredictor takes one uint8 HWC image on the GPU'
+        if (img.shape[1], img.shape[2], img.device) not in self._sets and len(self._sets) >= self.MAX_SIZES:
+            return dict(lane=None, done=None, result=self.det.predict(img, *self.pre)[0])      # a folder of many sizes: eager, synchronous
+        lanes = self._lane_set(img.shape[1], img.shape[2], img.device)
+        lane = lanes[self._turn % self.n_lanes]
+        self._turn += 1
+        if lane['ticket'] is not None and lane['ticket'].get('result') is None:
+            self.collect(lane['ticket'])                    # its pinned buffers are about to be reused
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(img.device))          # whatever produced / touched the image on the caller's stream (auto-contrast)
+        with torch.cuda.stream(lane['stream']):
+            lane['stream'].wait_event(ready)
+            lane['gin'].copy_(img)
+            img.record_stream(lane['stream'])
+            lane['graph'].replay()
+            for h, d in zip(lane['host'], lane['out']):
+                h.copy_(d, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(lane['stream'])
+        ticket = dict(lane=lane, done=done, result=None)
+        lane['ticket'] = ticket
+        return ticket
+
+    def collect(self, ticket):
+        if ticket['result'] is None:
+            ticket['done'].synchronize()
+            bbox, classes, cnt = (t.numpy() for t in ticket['lane']['host'])
+            k = int(cnt[0])
+            bbox, classes = bbox[:k].copy(), classes[:k].copy()
+            ticket['result'] = [bbox[classes == c] for c in range(len(self.det.classnames))]
+        return ticket['result']
+
+
 def detections_to_wire(boxes, scores, classes, width, height, out_width=None, out_height=None):
     """Device-side twin of Detectron2Det.predict (:119-131) + COCODetection.load_prediction
     (/root/reference/detnet/data/coco.py:229-252): the [x, y, w, h] integers, 5-decimal score and category id that

@@ -97,6 +97,15 @@ class TTA(nn.Module):
         scale = next((op[1] for op in self.plan if op[0] == 'resize'), 1.0)
         return float(scale), ('hflip',) in self.plan, ('vflip',) in self.plan
 
+    def graph_lanes(self, lanes=2):
+        """The streaming form of predict() (round 6): a GraphLanePredictor for the detector with this plan folded into its pre-processing, or None when
+        the plan cannot be folded (more than one resize) / the detector has no static-shape pass; undo the plan on its results with undo_plan()."""
+        fused = self._fused_pre() if hasattr(self.detector, 'predict_padded') and not getattr(self.detector, 'tta_min_sizes', None) else None
+        if fused is None:
+            return None
+        from .detectron2_det import GraphLanePredictor
+        return GraphLanePredictor(self.detector, *fused, lanes=lanes)
+
     def predict(self, x):
         fused = self._fused_pre() if hasattr(self.detector, 'predict_device') and torch.is_tensor(x) else None
         if fused is not None:
