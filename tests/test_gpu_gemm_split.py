@@ -422,3 +422,24 @@ def test_laboratory_knobs_are_ignored_without_wt_experiment():
     env['WT_EXPERIMENT'] = '1'
     r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ignored' not in r.stderr, r.stderr[-2000:]
+
+
+def test_planes_path_through_the_wide_stages_equals_the_f32_path(monkeypatch):
+    """WD_SPLIT_PLANES (off by default, profiles/r06_split_presplit.txt): block outputs of res4 / res5 as activation planes.  The GEMMs are bit-identical
+    either way; what remains between two runs of the backbone is the library offset convolution's atomics (not bit-repeatable on its own), so the
+    feature maps are compared at that level."""
+    from waymo_2d_tracking_amd.detnet.nn import cascade_rcnn
+    torch.manual_seed(3)
+    m = cascade_rcnn.CascadeRCNN(seed=2).cuda().eval()
+    x = torch.randn(1, 3, 256, 384, device='cuda').contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        monkeypatch.setattr(cascade_rcnn, 'SPLIT_PLANES', False)
+        ref = [f.clone() for f in m.backbone.bottom_up(x)]
+        again = [f.clone() for f in m.backbone.bottom_up(x)]
+        monkeypatch.setattr(cascade_rcnn, 'SPLIT_PLANES', True)
+        got = [f.clone() for f in m.backbone.bottom_up(x)]
+    assert len(got) == 4
+    for r, a, g in zip(ref, again, got):
+        assert g.shape == r.shape and torch.isfinite(g).all()
+        floor = float((a - r).abs().max())
+        assert float((g - r).abs().max()) <= max(4 * floor, 1e-5 * float(r.abs().max())), (float((g - r).abs().max()), floor)

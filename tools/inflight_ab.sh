@@ -34,5 +34,12 @@ case "$1" in
     run e2e_l3_b --inflight 3 --steps 10 --warmup 3
     run e2e_l1 --inflight 1 --steps 10 --warmup 3
     ;;
+  planes)
+    run e2e_f32act_a --steps 10 --warmup 3
+    WD_SPLIT_PLANES=1 run e2e_planes_a --steps 10 --warmup 3
+    run e2e_f32act_b --steps 10 --warmup 3
+    WD_SPLIT_PLANES=1 run e2e_planes_b --steps 10 --warmup 3
+    WD_SPLIT_PLANES=1 WD_SPLIT_PLANES_MIN_CH=512 run e2e_planes_res3_too --steps 10 --warmup 3
+    ;;
   *) run "$@" ;;
 esac

@@ -51,6 +51,20 @@ SPLIT_PARTS = set(os.environ.get('WD_SPLIT_PARTS', 'conv1x1,conv3x3,head,fc,offs
 OFFSET_SPLIT_MIN_ROWS = int(os.environ.get('WD_OFFSET_SPLIT_MIN_ROWS', '30000'))
 
 
+# Round 6, measured and OFF by default (profiles/r06_split_presplit.txt): inside a stage of >= SPLIT_PLANES_MIN_CH channels the block output travels as
+# pre-split activation planes (ops.gemm_split_io) - conv3 writes planes (residual read from planes), the next conv1 pulls them with LDS-DMA; the stage's last
+# block writes f32 for the next stage / the FPN.  Results are bit-identical to the f32 path.
+SPLIT_PLANES = os.environ.get('WD_SPLIT_PLANES', '0') == '1'
+SPLIT_PLANES_MIN_CH = int(os.environ.get('WD_SPLIT_PLANES_MIN_CH', '1024'))
+
+
+class PlanesAct:
+    """A block output that exists as activation planes only: (pixels, channels) planes + the NHWC geometry it stands for."""
+
+    def __init__(self, planes, n, h, w, c):
+        self.planes, self.n, self.h, self.w, self.c = planes, n, h, w, c
+
+
 # Parity tests set this to a list: every Bottleneck.forward then appends (conv1 output, offsets or None, conv2 output, block output, stride) - the
 # post-ReLU maps and sampling offsets from which oracle.detector_ref.block_decisions derives the block's discrete decisions (ReLU masks, bilinear cells).
 DECISION_LOG = None
@@ -235,7 +249,9 @@ class Bottleneck(nn.Module):
             split = self._off_split
         return ops.conv3x3_few(x, self._off_w2, self.conv2_offset.bias, 18, 1, deform_table, split=split)
 
-    def forward(self, x):
+    def forward(self, x, emit_planes=False):
+        if isinstance(x, PlanesAct) or emit_planes:
+            return self._forward_planes(x, emit_planes)
         sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)
         out = self.conv1(x, relu=True)
         rec = DECISION_LOG
@@ -274,6 +290,59 @@ class Bottleneck(nn.Module):
         return out3
 
 
+def _bottleneck_forward_planes(self, x, emit_planes):
+    """Inference, round 6 (SPLIT_PLANES): the same block with the block input / output as activation planes.  x: f32 NCHW view (first block of a stage) or
+    PlanesAct; returns PlanesAct when emit_planes else the f32 map.  conv1 and conv3 are wd_gemm_split_io calls; offset conv and deformable conv as ever."""
+    in_planes = isinstance(x, PlanesAct)
+    cout = self.conv3.weight.shape[0]
+    if in_planes:
+        assert self.shortcut is None and self.stride == 1
+        n, h, w, cin = x.n, x.h, x.w, x.c
+        m = n * h * w
+        o1, _ = ops.gemm_split_io(m, self.conv1.weight.shape[0], cin, self.conv1._split.get(self.conv1.weight), a_planes=x.planes, bias=self.conv1.bias, relu=True)
+        out = o1.view(n, h, w, -1).permute(0, 3, 1, 2)
+        sc = None
+    else:
+        sc = x if self.shortcut is None else self.shortcut(x, stride=self.stride)
+        out = self.conv1(x, relu=True)
+    table = None
+    if self.stride == 1 and self.conv2_weight.shape[1] in (16, 32):
+        offset, table = self.offset_conv(out, deform_table=True)
+    else:
+        offset = self.offset_conv(out) if self.stride == 1 else self.conv2_offset(out)
+    out = ops.deform_conv3x3(out, offset, self.packed_weight(), GROUPS, self.stride, 1, self.conv2_scale, self.conv2_bias, relu=True, table=table)
+    n, c, h, w = out.shape
+    m = n * h * w
+    a = out.permute(0, 2, 3, 1).reshape(m, c)
+    pw = self.conv3._split.get(self.conv3.weight)
+    if in_planes:
+        # block output into the residual's planes buffer (dead after this block), plus an f32 copy when the stage ends here
+        y, yp = ops.gemm_split_io(m, cout, c, pw, a=a, bias=self.conv3.bias, residual_planes=x.planes, relu=True, want_out=not emit_planes,
+                                  out_planes=x.planes if emit_planes else None, want_planes=False)
+    else:
+        r = sc if sc.is_contiguous(memory_format=torch.channels_last) else sc.contiguous(memory_format=torch.channels_last)
+        r = r.permute(0, 2, 3, 1).reshape(m, cout)
+        y, yp = ops.gemm_split_io(m, cout, c, pw, a=a, bias=self.conv3.bias, residual=r, relu=True, want_out=not emit_planes, want_planes=emit_planes)
+    if emit_planes:
+        return PlanesAct(yp, n, h, w, cout)
+    return y.view(n, h, w, cout).permute(0, 3, 1, 2)
+
+
+Bottleneck._forward_planes = _bottleneck_forward_planes
+
+
+def _run_stage(stage, x):
+    """One res stage; with SPLIT_PLANES (inference, split kernel on, wide stage) the block outputs inside the stage travel as activation planes."""
+    blocks = list(stage)
+    use = (SPLIT_PLANES and SPLIT_GEMM and not torch.is_grad_enabled() and x.is_cuda and DECISION_LOG is None and len(blocks) > 1
+           and blocks[0].conv3.weight.shape[0] >= SPLIT_PLANES_MIN_CH and blocks[0].deform and 'conv1x1' in SPLIT_PARTS)
+    if not use:
+        return stage(x)
+    for i, blk in enumerate(blocks):
+        x = blk(x, emit_planes=i + 1 < len(blocks))
+    return x
+
+
 class ResNeXt152FPN(nn.Module):
     def __init__(self, gen, offset_std=0.01):
         super().__init__()
@@ -300,7 +369,7 @@ class ResNeXt152FPN(nn.Module):
             x = self.stem(x, relu=True)
             x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
             c2 = self.res2(x)
-        c3 = self.res3(c2); c4 = self.res4(c3); c5 = self.res5(c4)
+        c3 = _run_stage(self.res3, c2); c4 = _run_stage(self.res4, c3); c5 = _run_stage(self.res5, c4)
         return [c2, c3, c4, c5]
 
     def top_down(self, feats):
