@@ -327,10 +327,10 @@ def run_rank(args, world, rank):
             if lanes is None:
                 store[image_id] = predict(img.unsqueeze(0))[0]        # uint8 HWC -> fused pre-processing kernel
                 continue
-            pending.append((image_id, lanes[0](img)))
-            if len(pending) > args.inflight:
+            if len(pending) >= args.inflight:                         # the oldest image's lane is the one this image will take
                 k, t = pending.pop(0)
                 store[k] = lanes[1](t)
+            pending.append((image_id, lanes[0](img)))
         for k, t in pending:
             store[k] = lanes[1](t)
     cols, tested = store.shard_columns()
