@@ -9,7 +9,7 @@ cd "$ROOT/waymo_2d_tracking_amd/csrc"
 mkdir -p variants/src
 cp det_gconv.hip det_deform.hip common.h variants/src/
 (cd "$ROOT" && sed 's#waymo_2d_tracking_amd/csrc/#waymo_2d_tracking_amd/csrc/variants/src/#g' tools/costream/victim_variants.patch | patch -p1 -s)
-sed -i 's#"../../include/#"../../../../include/#' variants/src/det_gconv.hip variants/src/det_deform.hip
+sed -i 's#"../../include/#"../../../../include/#' variants/src/det_gconv.hip variants/src/det_deform.hip variants/src/common.h
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math"
 build() {   # name, flags, units...
     name=$1; flags=$2; shift 2
@@ -27,8 +27,12 @@ build() {   # name, flags, units...
     rm -f $extra
     echo variants/lib_$name.so
 }
-build v_fz "-mllvm -amdgpu-waitcnt-forcezero" det_gconv.hip det_deform.hip
-build v_sync "-DWD_VICTIM_SYNC=1" det_gconv.hip det_deform.hip
-build v_m0 "-DWD_VICTIM_M0=1" det_gconv.hip
-build v_lb1 "-DWD_VICTIM_LB=1" det_gconv.hip det_deform.hip
-build v_check "-DWD_VICTIM_CHECK=1" det_gconv.hip
+[ -n "$SERIES2" ] || build v_fz "-mllvm -amdgpu-waitcnt-forcezero" det_gconv.hip det_deform.hip
+[ -n "$SERIES2" ] || build v_sync "-DWD_VICTIM_SYNC=1" det_gconv.hip det_deform.hip
+[ -n "$SERIES2" ] || build v_m0 "-DWD_VICTIM_M0=1" det_gconv.hip
+[ -n "$SERIES2" ] || build v_lb1 "-DWD_VICTIM_LB=1" det_gconv.hip det_deform.hip
+[ -n "$SERIES2" ] || build v_check "-DWD_VICTIM_CHECK=1" det_gconv.hip
+# round 6, second series: is the victims' LDS data LATE?  delay behind the fill barrier / no LDS-DMA at all
+build v_delay1 "-DWD_VICTIM_DELAY=1" det_gconv.hip det_deform.hip
+build v_delay8 "-DWD_VICTIM_DELAY=8" det_gconv.hip det_deform.hip
+build v_nodma "-DWD_VICTIM_NODMA=1" det_gconv.hip
