@@ -1,5 +1,7 @@
 """Where a launch of the split-operand GEMM spends its time, per workgroup: s_memtime stamps at start / main loop / epilogue / end
 (wd_gemm_split_debug_stamps).   python tools/gemm_split_stamps.py M N K [epilogue]"""
+# needs the debug library: WD_DEBUG_BUILD=1 python -m waymo_2d_tracking_amd.build, then WT_LIB_PATH=waymo_2d_tracking_amd/csrc/libwaymotrack_debug.so python tools/gemm_split_stamps.py ...
+
 import ctypes as C
 import os
 import sys

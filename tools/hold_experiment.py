@@ -1,6 +1,8 @@
 """How much does a side-stream kernel that merely HOLDS compute units cost the detector?  (tools only)
 The e2e bench loses 4.8 % against the detector alone while the SORT chunk kernel (20 one-wave workgroups, ~40 KB of LDS each, 23-31 ms
 per 10-frame chunk) runs next to it.  This script replaces SORT by wd_debug_hold with the same footprint and varies workgroups / LDS."""
+# needs the debug library: WD_DEBUG_BUILD=1 python -m waymo_2d_tracking_amd.build, then WT_LIB_PATH=waymo_2d_tracking_amd/csrc/libwaymotrack_debug.so python tools/hold_experiment.py ...
+
 import ctypes as C
 import os
 import sys

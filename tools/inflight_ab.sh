@@ -41,5 +41,11 @@ case "$1" in
     WD_SPLIT_PLANES=1 run e2e_planes_b --steps 10 --warmup 3
     WD_SPLIT_PLANES=1 WD_SPLIT_PLANES_MIN_CH=512 run e2e_planes_res3_too --steps 10 --warmup 3
     ;;
+  xmap)
+    run e2e_xmap0_a --steps 10 --warmup 3
+    WD_SPLIT_XMAP=1 run e2e_xmap1_a --steps 10 --warmup 3
+    run e2e_xmap0_b --steps 10 --warmup 3
+    WD_SPLIT_XMAP=1 run e2e_xmap1_b --steps 10 --warmup 3
+    ;;
   *) run "$@" ;;
 esac

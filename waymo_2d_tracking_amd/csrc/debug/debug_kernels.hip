@@ -1,12 +1,12 @@
 // Laboratory kernels: NOT part of the product library.  Built into libwaymotrack.so only when WD_DEBUG_BUILD=1 is set for
-// `python -m waymo_2d_tracking_amd.build` (tools/costream/*, tools/hold_experiment.py, tools/diag_*.py use them); declared in
+// `python -m waymo_2d_tracking_amd.build` (tools/costream/*, tools/hold_experiment.py, tools/archive/diag_*.py use them); declared in
 // csrc/debug/waymodet_debug.h, never in include/.
 #include "../common.h"
 #include "waymodet_debug.h"
 #include <cstdlib>
 #include <cstring>
 
-// ---- diagnostics: a "canary" workgroup for co-residency experiments (tools/diag_canary.py) ----------------------------------------------
+// ---- diagnostics: a "canary" workgroup for co-residency experiments (tools/archive/diag_canary.py) ----------------------------------------------
 // 256 threads fill `lds_bytes` of LDS and 16 registers with a pattern, keep an f32 FMA chain and an f32 MFMA chain going for `spins` rounds
 // and count, per kind, how often a value comes back different: flags[0] LDS, [1] registers, [2] VALU chain, [3] MFMA chain, [4] workgroups run.
 namespace {
