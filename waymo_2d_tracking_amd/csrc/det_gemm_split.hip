@@ -760,7 +760,10 @@ __global__ __launch_bounds__(256) void gemm_split_pack_batch_kernel(const WdSpli
 }
 
 // out = act(sum over the K slices in slice order + bias + residual): deterministic, one float4 per thread; residual / output as f32 and / or
-// as activation planes, like the tile epilogue
+// as activation planes, like the tile epilogue.  (Round 6 tried the one-launch form - every slice counts itself in on a per-stream counter, the last one
+// to arrive sums the tile - and measured it SLOWER: training step 71.2 -> 83.3 ms, e2e 42.3 -> 39.9 frames/s, bit-identical results.  The partial tiles
+// must be visible across XCDs, and the device-scope release / acquire fences that takes (__threadfence: an L2 write-back per workgroup) cost far more
+// than the 10 us launch they save; profiles/r06_split_presplit.txt, last section.)
 __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float4* __restrict__ part, int splitk, long mn4, int n4, const float4* __restrict__ bias,
                                                                 const float* __restrict__ residual, const unsigned char* __restrict__ resp, long ldc, int relu,
                                                                 float* __restrict__ out, unsigned char* __restrict__ outp) {
