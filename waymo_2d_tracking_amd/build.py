@@ -43,14 +43,11 @@ UNITS = {
     'det_backward.hip': ['-munsafe-fp-atomics'],
     'det_deform_bwd.hip': ['-munsafe-fp-atomics'],     # fused deformable backward: global float atomics for the dW / dX / dOffset partial sums
 }
-# laboratory kernels (canaries, occupants, the matrix-instruction burner of tools/costream/): only with WD_DEBUG_BUILD=1, never in the product library
-# -> csrc/libwaymotrack_debug.so with its own objects (*.dbg.o); load it with WT_LIB_PATH
-DEBUG_BUILD = os.environ.get('WD_DEBUG_BUILD') == '1'
-OBJ_EXT = '.dbg.o' if DEBUG_BUILD else '.o'
-if DEBUG_BUILD:
-    UNITS['debug/debug_kernels.hip'] = []
-    COMMON += ['-DWD_DEBUG=1']
-    LIB = os.path.join(CSRC, 'libwaymotrack_debug.so')
+# Laboratory kernels (canaries, occupants, the matrix-instruction burner of tools/costream/, per-workgroup stamps of the split kernel): never in the product
+# library.  build_debug() makes csrc/libwaymotrack_debug.so = the product's objects, with det_gemm_split.hip rebuilt under -DWD_DEBUG and
+# debug/debug_kernels.hip added (objects *.dbg.o); load it with WT_LIB_PATH.  `WD_DEBUG_BUILD=1 python -m waymo_2d_tracking_amd.build` builds both.
+DEBUG_UNITS = {'det_gemm_split.hip': [], 'debug/debug_kernels.hip': []}
+DEBUG_LIB = os.path.join(CSRC, 'libwaymotrack_debug.so')
 
 
 def _newer(target, sources):
@@ -68,7 +65,7 @@ def build(force=False, verbose=True):
     jobs = []
     for u in units:
         src = os.path.join(CSRC, u)
-        obj = os.path.join(CSRC, os.path.basename(u).replace('.hip', OBJ_EXT))
+        obj = os.path.join(CSRC, os.path.basename(u).replace('.hip', '.o'))
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
             jobs.append([HIPCC] + COMMON + UNITS[u] + ['-c', src, '-o', obj])
@@ -91,6 +88,34 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_debug(force=False, verbose=True):
+    """libwaymotrack_debug.so (see DEBUG_UNITS); builds the product library first."""
+    build(force, verbose)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(CSRC, 'debug', 'waymodet_debug.h')]
+    headers += [os.path.join(HERE, '..', 'include', f) for f in os.listdir(os.path.join(HERE, '..', 'include'))]
+    objs = [os.path.join(CSRC, os.path.basename(u).replace('.hip', '.o')) for u in UNITS if u not in DEBUG_UNITS]
+    jobs = []
+    for u, flags in DEBUG_UNITS.items():
+        src, obj = os.path.join(CSRC, u), os.path.join(CSRC, os.path.basename(u).replace('.hip', '.dbg.o'))
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            jobs.append([HIPCC] + COMMON + ['-DWD_DEBUG=1'] + UNITS.get(u, []) + flags + ['-c', src, '-o', obj])
+    for cmd in jobs:
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stderr[-6000:]))
+    if jobs or force or _newer(DEBUG_LIB, objs):
+        r = subprocess.run([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', DEBUG_LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stderr[-6000:])
+    return DEBUG_LIB
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if os.environ.get('WD_DEBUG_BUILD') == '1':
+        print(build_debug(force='--force' in sys.argv))
+    else:
+        build(force='--force' in sys.argv)
     print(LIB)
