@@ -95,3 +95,12 @@ def test_split_io_struct_layout_matches_the_header():
     assert C.sizeof(ops._SplitIO) == 64
     for (name, ctype), decl in zip(ops._SplitIO._fields_, [d.strip() for d in body.split(';') if d.strip()]):
         assert (ctype is C.c_long) == decl.startswith('long'), (name, decl)
+
+
+def test_product_library_exports_no_laboratory_entry_points(lib):
+    """Round 6: canary / occupant / burner kernels and the per-workgroup stamps live in csrc/debug/ and libwaymotrack_debug.so only."""
+    for name in ('wd_debug_canary', 'wd_debug_occupy', 'wd_debug_hold', 'wd_debug_mfma_burn', 'wd_gemm_split_debug_stamps'):
+        assert not hasattr(lib, name), name
+    from waymo_2d_tracking_amd import build
+    dbg = ctypes.CDLL(build.build_debug(verbose=False))
+    assert all(hasattr(dbg, n) for n in ('wd_debug_mfma_burn', 'wd_gemm_split_debug_stamps', 'wd_gemm_split_f32'))
