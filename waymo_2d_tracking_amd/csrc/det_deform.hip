@@ -738,6 +738,13 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int cg, int cout
 
 }  // namespace
 
+int wt::victim_regs_deform64() {
+    hipFuncAttributes at{};
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(deform_conv3x3_kernel<64, true>)) != hipSuccess) return 0;
+    return (at.numRegs + 7) / 8 * 8;
+}
+
+
 int wd_deform_pp_launch(const float* x, const float* offset, const float* packed_weight, const float* scale,
                         const float* bias, int relu, int batch, int h, int w, int c, int cg, int stride, hipStream_t stream, float* y,
                         const void* table);

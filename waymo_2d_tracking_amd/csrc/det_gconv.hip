@@ -134,6 +134,12 @@ __global__ __launch_bounds__(256, 2) void grouped_conv3x3_c8_kernel(const float*
 
 }  // namespace
 
+int wt::victim_regs_grouped_conv() {
+    hipFuncAttributes at{};
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(grouped_conv3x3_c8_kernel)) != hipSuccess) return 0;
+    return (at.numRegs + 7) / 8 * 8;
+}
+
 // Plain grouped 3x3 conv, 8 channels per group, stride 1, pad 1 (called by wd_deform_conv3x3_f32 when offset == NULL).
 int wd_grouped_conv3x3_c8_launch(const float* x, const float* packed_weight, const float* scale, const float* bias, int relu,
                                  int batch, int h, int w, int c, hipStream_t stream, float* y) {

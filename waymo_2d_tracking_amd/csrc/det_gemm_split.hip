@@ -862,17 +862,21 @@ Plan pick_plan(long M, int N, int K, bool allow_split) {
 long long* g_stamps = nullptr;           // diagnostics (wd_gemm_split_debug_stamps)
 #endif
 
-// The co-residency rule of pick_plan, checked on what was actually compiled: a workgroup of this kernel puts two waves on every SIMD; a foreign
-// wave of 230 registers (the smaller of the two kernels known to return wrong results beside bf16 matrix waves) must not fit into the
-// 512-register file next to them.  VGPRs are allocated in blocks of 8.
+// The co-residency rule of pick_plan, checked on what was actually compiled: a workgroup of this kernel puts two waves on every SIMD; a wave
+// of the two kernels known to return wrong results beside bf16 matrix waves (their register counts are read from the compiled kernels too) must not fit
+// into the 512-register file next to them.  VGPRs are allocated in blocks of 8.
 int occupancy_guard(const void* fn, int mt) {
     hipFuncAttributes at{};
     WT_HIP(hipFuncGetAttributes(&at, fn));
     const int alloc = (at.numRegs + 7) / 8 * 8;
-    if (2 * alloc + 232 <= 512 && !experiment_mode()) {
-        wt::set_error("split-operand kernel with %d row blocks was compiled to %d registers: a 230-register wave of another kernel fits beside two of its "
-                      "waves on a SIMD, which is the co-residency that corrupts deform_conv3x3_kernel<64> / grouped_conv3x3_c8_kernel "
-                      "(profiles/r06_costream_victim_side.txt); refused (WT_EXPERIMENT=1 overrides)", mt, at.numRegs);
+    // the smaller of the two vulnerable kernels AS COMPILED (today 232 and 256 allocated registers); 232 when the query fails
+    int victim = 232;
+    const int g = wt::victim_regs_grouped_conv(), d = wt::victim_regs_deform64();
+    if (g > 0 && d > 0) victim = g < d ? g : d;
+    if (2 * alloc + victim <= 512 && !experiment_mode()) {
+        wt::set_error("split-operand kernel with %d row blocks was compiled to %d registers: a %d-register wave of deform_conv3x3_kernel<64> / "
+                      "grouped_conv3x3_c8_kernel fits beside two of its waves on a SIMD, which is the co-residency that corrupts those kernels "
+                      "(profiles/r06_costream_victim_side.txt); refused (WT_EXPERIMENT=1 overrides)", mt, at.numRegs, victim);
         return WT_ERR_INVALID;
     }
     return WT_OK;
