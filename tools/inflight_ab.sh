@@ -47,5 +47,13 @@ case "$1" in
     run e2e_xmap0_b --steps 10 --warmup 3
     WD_SPLIT_XMAP=1 run e2e_xmap1_b --steps 10 --warmup 3
     ;;
+  instr)
+    run e2e_instr_all_a --steps 10 --warmup 3
+    WT_BENCH_INSTRUMENT_STEPS=2 run e2e_instr_2_a --steps 10 --warmup 3
+    WT_BENCH_INSTRUMENT_STEPS=0 run e2e_instr_0_a --steps 10 --warmup 3
+    run e2e_instr_all_b --steps 10 --warmup 3
+    WT_BENCH_INSTRUMENT_STEPS=2 run e2e_instr_2_b --steps 10 --warmup 3
+    WT_BENCH_INSTRUMENT_STEPS=0 run e2e_instr_0_b --steps 10 --warmup 3
+    ;;
   *) run "$@" ;;
 esac
