@@ -443,3 +443,48 @@ def test_planes_path_through_the_wide_stages_equals_the_f32_path(monkeypatch):
         assert g.shape == r.shape and torch.isfinite(g).all()
         floor = float((a - r).abs().max())
         assert float((g - r).abs().max()) <= max(4 * floor, 1e-5 * float(r.abs().max())), (float((g - r).abs().max()), floor)
+
+
+def test_position_major_convolution_tiles_equal_the_plain_row_order(ops, tmp_path):
+    """Round 6: 3x3 / stride 1 / pad 1 convolutions over many small maps (the box heads: 1000 ROIs x 7 x 7) run with position-major tiles that SKIP the taps in
+    the zero padding (gemm_split_kernel<MT, 3>).  The walked taps are summed in the same order, so the result must be bit-identical to the plain row order
+    (WD_SPLIT_NO_POSMAJOR=1, a laboratory switch, in a fresh process) - with bias / residual / ReLU, ragged map counts, non-square maps, N % 256 != 0 - and
+    within the float64 gate."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = [(1000, 256, 7, 7, 256, 1), (300, 64, 5, 9, 32, 0), (257, 128, 3, 3, 64, 1), (513, 64, 9, 9, 288, 1)]
+    code = ("import sys, torch\n"
+            "from waymo_2d_tracking_amd.detnet.nn import ops\n"
+            "out = {}\n"
+            "for b, c, h, w, n, epi in %r:\n"
+            "    torch.manual_seed(b + c + n)\n"
+            "    x = torch.randn(b, c, h, w, device='cuda').contiguous(memory_format=torch.channels_last)\n"
+            "    wt = torch.randn(n, c, 3, 3, device='cuda') / (3 * c ** 0.5)\n"
+            "    bias = torch.randn(n, device='cuda') if epi else None\n"
+            "    res = torch.randn(b, n, h, w, device='cuda').contiguous(memory_format=torch.channels_last) if epi else None\n"
+            "    out[(b, c, h, w, n)] = ops.conv_split(x, ops.split_pack_weight(wt), n, 3, 1, 1, bias, res, bool(epi)).cpu()\n"
+            "torch.save(out, sys.argv[1])\n" % (shapes,))
+    env = dict(os.environ, WD_SPLIT_NO_POSMAJOR='1', WT_EXPERIMENT='1')
+    ref_file = str(tmp_path / 'plain.pt')
+    r = subprocess.run([sys.executable, '-c', code, ref_file], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = torch.load(ref_file)
+    for b, c, h, w, n, epi in shapes:
+        torch.manual_seed(b + c + n)
+        x = torch.randn(b, c, h, w, device='cuda').contiguous(memory_format=torch.channels_last)
+        wt = torch.randn(n, c, 3, 3, device='cuda') / (3 * c ** 0.5)
+        bias = torch.randn(n, device='cuda') if epi else None
+        res = torch.randn(b, n, h, w, device='cuda').contiguous(memory_format=torch.channels_last) if epi else None
+        y = ops.conv_split(x, ops.split_pack_weight(wt), n, 3, 1, 1, bias, res, bool(epi))
+        import ctypes as C
+        from waymo_2d_tracking_amd import _lib
+        if int(_lib.lib().wd_gemm_split_workspace(C.c_long(b * h * w), C.c_int(n), C.c_int(9 * c))) == 0:
+            assert torch.equal(y.cpu(), ref[(b, c, h, w, n)]), (b, c, h, w, n)            # same taps, same order
+        else:                                       # the plain row order cuts K into slices for this shape: another summation tree
+            assert float((y.cpu() - ref[(b, c, h, w, n)]).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())), (b, c, h, w, n)
+        y64 = F.conv2d(x.double(), wt.double(), None if bias is None else bias.double(), 1, 1)
+        if epi:
+            y64 = (y64 + res.double()).relu()
+        assert float((y.double() - y64).abs().max()) <= 2e-5 * max(1.0, float(y64.abs().max()))

@@ -55,5 +55,19 @@ case "$1" in
     WT_BENCH_INSTRUMENT_STEPS=2 run e2e_instr_2_b --steps 10 --warmup 3
     WT_BENCH_INSTRUMENT_STEPS=0 run e2e_instr_0_b --steps 10 --warmup 3
     ;;
+  posmajor)
+    for mt in 4 5 6; do
+      WD_SPLIT_MT=$mt python tools/conv_split_one.py 1000 256 7 7 256 2>&1 | grep conv3x3 | sed "s/^/position-major  /"
+      WD_SPLIT_MT=$mt WD_SPLIT_NO_POSMAJOR=1 python tools/conv_split_one.py 1000 256 7 7 256 2>&1 | grep conv3x3 | sed "s/^/plain row order /"
+    done
+    run e2e_posmajor_a --steps 10 --warmup 3
+    WD_SPLIT_NO_POSMAJOR=1 run e2e_plainrows_a --steps 10 --warmup 3
+    run e2e_posmajor_b --steps 10 --warmup 3
+    WD_SPLIT_NO_POSMAJOR=1 run e2e_plainrows_b --steps 10 --warmup 3
+    run train_posmajor_a --stage train --steps 8 --warmup 4
+    WD_SPLIT_NO_POSMAJOR=1 run train_plainrows_a --stage train --steps 8 --warmup 4
+    run train_posmajor_b --stage train --steps 8 --warmup 4
+    WD_SPLIT_NO_POSMAJOR=1 run train_plainrows_b --stage train --steps 8 --warmup 4
+    ;;
   *) run "$@" ;;
 esac

@@ -107,8 +107,11 @@ __device__ __forceinline__ size_t planes_offset(int row, int col, int ncols) {
 //     hi + mid + lo: exactly the f32 value the planes were split from).
 constexpr int LDC = BN + 8;
 
+// Row mapping (round 6, position-major convolution tiles): tile row r stands for matrix row m0 + r, valid while < mlim, and lives at output row
+// (m0 + r) * row_mul + row_add (plain tiles: mlim = M, row_mul = 1, row_add = 0).
 template <int MT>
-__device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char* smem, const f32x16 (&acc)[MT], int m0, int n0, int wave, int lane) {
+__device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char* smem, const f32x16 (&acc)[MT], int m0, int n0, int wave, int lane, int mlim,
+                                               int row_mul = 1, int row_add = 0) {
     const int rr = lane & 31, rg = lane >> 5;
     float* ct = reinterpret_cast<float*>(smem);
     const int ncols = p.N - n0 < BN ? p.N - n0 : BN;            // valid columns of this tile (multiple of 32)
@@ -140,15 +143,16 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
                 for (int j = 0; j < RPW; ++j) {
                     const int r = wave + 8 * j, row = m0 + 32 * i0 + r;
                     rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < nrows && row < p.M && c4 < ncols) rv[j] = *reinterpret_cast<const float4*>(p.residual + (size_t)row * p.ldc + n0 + c4);
+                    if (r < nrows && row < mlim && c4 < ncols)
+                        rv[j] = *reinterpret_cast<const float4*>(p.residual + (size_t)(row * row_mul + row_add) * p.ldc + n0 + c4);
                 }
             } else if (p.resp) {
 #pragma unroll
                 for (int j = 0; j < RPW; ++j) {
                     const int r = wave + 8 * j, row = m0 + 32 * i0 + r;
                     rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < nrows && row < p.M && c4 < ncols) {
-                        const unsigned char* q = p.resp + planes_offset(row, n0 + c4, p.N);
+                    if (r < nrows && row < mlim && c4 < ncols) {
+                        const unsigned char* q = p.resp + planes_offset(row * row_mul + row_add, n0 + c4, p.N);
                         const uint2 h = *reinterpret_cast<const uint2*>(q), m = *reinterpret_cast<const uint2*>(q + 2048),
                                     l = *reinterpret_cast<const uint2*>(q + 4096);
                         rv[j] = make_float4((bf_lo(h.x) + bf_lo(m.x)) + bf_lo(l.x), (bf_hi(h.x) + bf_hi(m.x)) + bf_hi(l.x),
@@ -160,12 +164,12 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const int r = wave + 8 * j, row = m0 + 32 * i0 + r;
-                if (r < nrows && row < p.M && c4 < ncols) {
+                if (r < nrows && row < mlim && c4 < ncols) {
                     float4 v = *reinterpret_cast<const float4*>(ct + r * LDC + c4);
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (p.residual || p.resp) { v.x += rv[j].x; v.y += rv[j].y; v.z += rv[j].z; v.w += rv[j].w; }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + n0 + c4) = v;
+                    *reinterpret_cast<float4*>(p.out + (size_t)(row * row_mul + row_add) * p.ldc + n0 + c4) = v;
                 }
             }
         }
@@ -185,7 +189,7 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
         for (int j = 0; j < UPW; ++j) {
             const int u = wave + 8 * j;
             rq[j][0] = rq[j][1] = rq[j][2] = make_uint4(0u, 0u, 0u, 0u);
-            if (u < nunits && m0 + 32 * (i0 + u / (2 * ncb)) < p.M) {        // (row blocks past the matrix do not exist in the planes buffers)
+            if (u < nunits && m0 + 32 * (i0 + u / (2 * ncb)) < mlim) {       // (row blocks past the matrix do not exist in the planes buffers)
                 const int rbi = u / (2 * ncb), cb = (u >> 1) - rbi * ncb, h = u & 1;
                 const int r = 16 * h + ur, row = m0 + 32 * (i0 + rbi) + r;
                 const int c8 = 8 * ((lane & 3) ^ ((r >> 2) & 3)), col = n0 + 32 * cb + c8;
@@ -194,7 +198,7 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
                     rq[j][0] = *reinterpret_cast<const uint4*>(q);
                     rq[j][1] = *reinterpret_cast<const uint4*>(q + 2048);
                     rq[j][2] = *reinterpret_cast<const uint4*>(q + 4096);
-                } else if (p.residual && row < p.M) {
+                } else if (p.residual && row < mlim) {
                     const uint4* q = reinterpret_cast<const uint4*>(p.residual + (size_t)row * p.ldc + col);
                     rq[j][0] = q[0];
                     rq[j][1] = q[1];
@@ -205,7 +209,7 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
 #pragma unroll
         for (int j = 0; j < UPW; ++j) {
             const int u = wave + 8 * j;
-            if (u < nunits && m0 + 32 * (i0 + u / (2 * ncb)) < p.M) {
+            if (u < nunits && m0 + 32 * (i0 + u / (2 * ncb)) < mlim) {
                 const int rbi = u / (2 * ncb), cb = (u >> 1) - rbi * ncb, h = u & 1;
                 const int r = 16 * h + ur, row = m0 + 32 * (i0 + rbi) + r;
                 const int c8 = 8 * ((lane & 3) ^ ((r >> 2) & 3)), col = n0 + 32 * cb + c8;
@@ -230,7 +234,7 @@ __device__ __forceinline__ void split_epilogue(const SplitArgs& p, unsigned char
                     v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
                     v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
                 }
-                if (p.out && row < p.M) {
+                if (p.out && row < mlim) {
                     float4* d = reinterpret_cast<float4*>(p.out + (size_t)row * p.ldc + col);
                     d[0] = v0; d[1] = v1;
                 }
@@ -276,20 +280,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     constexpr int BUF = 3 * PLANE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int id = xcd_tile_id(p.tiles_m * p.tiles_n * p.splitk);
-    if (id < 0) return;
+    constexpr bool CONV = MODE == 1 || MODE == 3;       // A rows are NHWC pixels
+    constexpr bool PM = MODE == 3;                       // position-major tiles (see below)
+    int id = PM ? (int)blockIdx.x : xcd_tile_id(p.tiles_m * p.tiles_n * p.splitk);
+    if (id < 0 || (PM && id >= p.tiles_m * p.tiles_n)) return;
 #ifdef WD_DEBUG
     long long t_start = 0, r_start = 0, t_main = 0, t_epi = 0;
     if (p.stamps) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
     const int id_stamp = id;
 #endif
     // split-K: the slices of one tile are neighbours (same XCD); slice kz covers K steps [k0, k0 + nk)
-    const int kz = id % p.splitk;
-    id /= p.splitk;
+    const int kz = PM ? 0 : id % p.splitk;
+    if (!PM) id /= p.splitk;
     int tm, tn;
-    if (p.xmap == 0) { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; } else { tn = id / p.tiles_m; tm = id - tn * p.tiles_m; }
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nk_all = p.K / 32;
+    if (p.xmap == 0 || PM) { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; } else { tn = id / p.tiles_m; tm = id - tn * p.tiles_m; }
+    int m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int kc = CONV ? p.C / 32 : 1;           // K steps per tap
+    // MODE 3 (round 6): POSITION-MAJOR tiles of a 3x3 / stride 1 / pad 1 convolution over many small maps (the box heads: 1000 ROIs x 7 x 7).  A tile = ONE
+    // output position (y, x) of up to BM consecutive maps, so whether a tap falls into the zero padding is the same for every row of the tile and the K
+    // steps of such taps are SKIPPED (18 % of the (row, tap) pairs of a 7 x 7 map; the plain row order computes them on zero operands).  Tiles are
+    // numbered longest first - the (H-2)(W-2) interior positions (9 taps), then the edges (6), then the corners (4), chunk-major inside a class - and are
+    // dispatched in that order without the per-XCD ranges of the other modes, so the short tiles fill the tail.  The remaining taps are summed in the same
+    // order as ever: bit-identical results.  m0 = first map of the tile; matrix row of (map b, position) = b * H * W + y * W + x.
+    int pm_y = 0, pm_x = 0, pm_nvt = 9;
+    unsigned long long pm_taps = 0x876543210ull;  // the valid taps, one nibble each, ascending
+    if (PM) {
+        const int nch = (p.M / (p.H * p.W) + BM - 1) / BM;                 // map chunks per position (M = maps x H x W)
+        const int wi = p.W - 2, hi = p.H - 2, ni = wi * hi, ne = 2 * wi + 2 * hi;
+        int t = tm, c, q;
+        if (t < ni * nch) { c = t / ni; q = t - c * ni; pm_y = 1 + q / wi; pm_x = 1 + q - (q / wi) * wi; }
+        else if (t < (ni + ne) * nch) {
+            t -= ni * nch; c = t / ne; q = t - c * ne;
+            if (q < wi) { pm_y = 0; pm_x = 1 + q; }
+            else if (q < 2 * wi) { pm_y = p.H - 1; pm_x = 1 + q - wi; }
+            else if (q < 2 * wi + hi) { pm_x = 0; pm_y = 1 + q - 2 * wi; }
+            else { pm_x = p.W - 1; pm_y = 1 + q - 2 * wi - hi; }
+        } else { t -= (ni + ne) * nch; c = t >> 2; q = t & 3; pm_y = (q >> 1) ? p.H - 1 : 0; pm_x = (q & 1) ? p.W - 1 : 0; }
+        m0 = c * BM;
+        pm_taps = 0; pm_nvt = 0;
+        for (int tp = 0; tp < 9; ++tp) {
+            const int yy = pm_y + tp / 3 - 1, xx = pm_x + tp % 3 - 1;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) { pm_taps |= (unsigned long long)tp << (4 * pm_nvt); ++pm_nvt; }
+        }
+    }
+    auto pm_tap = [&](int i) { return (int)((pm_taps >> (4 * i)) & 15ull); };
+    const int nk_all = PM ? pm_nvt * kc : p.K / 32;
     const int per = (nk_all + p.splitk - 1) / p.splitk;
     const int k0 = kz * per;
     const int nk = (k0 + per <= nk_all) ? per : nk_all - k0;
@@ -301,6 +337,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         int m = m0 + srow + 32 * i;
+        if (PM) {
+            const int maps = p.M / (p.H * p.W);
+            m = m < maps ? m : maps - 1;                 // m = map index
+            aoff[i] = (unsigned)(((m * p.H + pm_y - 1) * p.W + pm_x - 1) * p.C + 2 * sk2);
+            vmask[i] = 0x1ffu;                           // the taps that are walked are valid for every row
+            continue;
+        }
         m = m < p.M ? m : p.M - 1;
         if (MODE == 0) {
             aoff[i] = (unsigned)(m * p.lda) + 2u * sk2;
@@ -319,14 +362,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
             vmask[i] = vm;
         }
     }
-    const int kc = (MODE == 1) ? p.C / 32 : 1;    // K steps per tap
     float2 araw[MT];
     auto a_fetch = [&](int kt, int i) -> float2 {   // row block i of K step kt (clamped)
         kt = k0 + (kt < nk ? kt : nk - 1);
         if (MODE == 0) {
             return *reinterpret_cast<const float2*>(p.a + (size_t)(aoff[i] + (unsigned)(kt * 32)));
         } else {
-            const int tap = kt / kc, cb = kt - tap * kc;
+            const int ti = kt / kc, cb = kt - ti * kc;
+            const int tap = PM ? pm_tap(ti) : ti;
             const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
             const unsigned delta = (unsigned)((dy * p.W + dx) * p.C + cb * 32);
             const bool ok = ((vmask[i] >> tap) & 1u) != 0;
@@ -341,8 +384,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     // profiles/r05_split_pmc_conv.txt, r05_split_conv_cursor.txt)
     int f_idx = 0, f_tap = 0, f_cb = 0;
     unsigned f_delta = 0;
+    int f_act = 0;                                  // the tap f_tap stands for (MODE 3: f_tap counts the WALKED taps)
     auto f_place = [&]() {
-        const int dy = p.ksize == 3 ? (f_tap * 11) >> 5 : 0, dx = f_tap - dy * p.ksize;      // tap / 3 for tap < 9
+        f_act = PM ? pm_tap(f_tap) : f_tap;
+        const int dy = p.ksize == 3 ? (f_act * 11) >> 5 : 0, dx = f_act - dy * p.ksize;      // tap / 3 for tap < 9
         f_delta = (unsigned)((dy * p.W + dx) * p.C + f_cb * 32);
     };
     auto f_set = [&](int kt) {
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
         }
     };
     auto a_fetch_cur = [&](int i) -> float2 {
-        const bool ok = ((vmask[i] >> f_tap) & 1u) != 0;
+        const bool ok = ((vmask[i] >> f_act) & 1u) != 0;
         const unsigned off = ok ? aoff[i] + f_delta : 2u * sk2;
         const float2 v = *reinterpret_cast<const float2*>(p.a + (size_t)off);
         return ok ? v : make_float2(0.f, 0.f);
@@ -383,6 +428,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
     bf16x8 wf[2][3];
     auto w_load = [&](int sub, int slot) {
         sub = 2 * k0 + (sub < nsub ? sub : nsub - 1);
+        if (PM) {                                   // walked K step -> the weight's K step: (walked tap index, rest) -> (tap, rest)
+            const int ti = sub / (2 * kc);
+            sub = pm_tap(ti) * 2 * kc + (sub - ti * 2 * kc);
+        }
         const uint4* q = wbase + (size_t)sub * 192;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) wf[slot][pl] = __builtin_bit_cast(bf16x8, q[pl * 64]);
@@ -434,11 +483,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
         af[i][pl] = *reinterpret_cast<const bf16x8*>(smem + (addr) + (pl) * PLANE + i * 2048);
     // A rows two K steps ahead (a second register set): araw = step kt + 2 (split now), aahead = step kt + 3, reload with step kt + 4
 #define SPLIT_ROW(i_)                                                                                         \
-    if ((i_) < MT) { a_store_row(wr, (i_)); araw[(i_)] = aahead[(i_)]; aahead[(i_)] = (MODE == 1) ? a_fetch_cur((i_)) : a_fetch(kt + 4, (i_)); }
+    if ((i_) < MT) { a_store_row(wr, (i_)); araw[(i_)] = aahead[(i_)]; aahead[(i_)] = CONV ? a_fetch_cur((i_)) : a_fetch(kt + 4, (i_)); }
     RD(rofs0, 2) RD(rofs0, 1) RD(rofs0, 0)
     SB;
     int cur = 0, nxt = BUF, wr = 2 * BUF;
-    if (MODE == 1) f_set(4);
+    if (CONV) f_set(4);
     for (int kt = 0; kt < nk; ++kt) {
         const int a1 = cur + rofs1, a0n = nxt + rofs0;
         // sub-step 0 (fragments in registers); its slots request sub-step 1's fragments of the same buffer.  The W fragments of a sub-step are
@@ -462,7 +511,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
         __builtin_amdgcn_s_barrier();
         SB;
         const int t = cur; cur = nxt; nxt = wr; wr = t;
-        if (MODE == 1) f_advance(kt + 5);         // the next iteration fetches K step kt + 5
+        if (CONV) f_advance(kt + 5);              // the next iteration fetches K step kt + 5
     }
 #undef SPLIT_ROW
 #ifdef WD_DEBUG
@@ -475,9 +524,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_kernel(const SplitArgs
         q.out = p.part + (size_t)kz * p.M * p.N;
         q.ldc = p.N;
         q.bias = nullptr; q.residual = nullptr; q.resp = nullptr; q.outp = nullptr; q.relu = 0;
-        split_epilogue<MT>(q, smem, acc, m0, n0, wave, lane);
+        split_epilogue<MT>(q, smem, acc, m0, n0, wave, lane, p.M);
+    } else if (PM) {
+        split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane, p.M / (p.H * p.W), p.H * p.W, pm_y * p.W + pm_x);
     } else {
-        split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane);
+        split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane, p.M);
     }
 #ifdef WD_DEBUG
     if (p.stamps && tid == 0) {
@@ -652,9 +703,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_split_planes_kernel(const Sp
         q.out = p.part + (size_t)kz * p.M * p.N;
         q.ldc = p.N;
         q.bias = nullptr; q.residual = nullptr; q.resp = nullptr; q.outp = nullptr; q.relu = 0;
-        split_epilogue<MT>(q, smem, acc, m0, n0, wave, lane);
+        split_epilogue<MT>(q, smem, acc, m0, n0, wave, lane, p.M);
     } else {
-        split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane);
+        split_epilogue<MT>(p, smem, acc, m0, n0, wave, lane, p.M);
     }
 #ifdef WD_DEBUG
     if (p.stamps && tid == 0) {
@@ -889,7 +940,7 @@ int launch(const SplitArgs& a, hipStream_t stream) {
     constexpr size_t lds_ring = (MODE == 2 ? 4u : 3u) * 3u * 32u * MT * 64u;
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     const void* fn = MODE == 2 ? reinterpret_cast<const void*>(gemm_split_planes_kernel<MT>)
-                               : reinterpret_cast<const void*>(gemm_split_kernel<MT, MODE == 2 ? 0 : MODE>);
+                               : reinterpret_cast<const void*>(gemm_split_kernel<MT, MODE == 2 ? 0 : MODE>);      // MODE 3: position-major convolution tiles
     static wt::OncePerDevice attr;
     const int dev = wt::device_index();
     if (attr.needed(dev)) {
@@ -934,6 +985,37 @@ int dispatch(SplitArgs& a, void* workspace, size_t workspace_bytes, hipStream_t 
                        (const float4*)a.bias, a.residual, a.resp, a.ldc, a.relu, a.out, a.outp);
     WT_HIP(hipGetLastError());
     return WT_OK;
+}
+
+// Position-major tiles (MODE 3) for a 3x3 / stride 1 / pad 1 convolution over many small maps: tile height from the same cost model, summed over the three
+// position classes (9 / 6 / 4 walked taps) and spread over the chip (the launch is several waves of unequal tiles, longest first).
+int dispatch_position_major(SplitArgs& a, hipStream_t stream) {
+#ifdef WD_DEBUG
+    a.stamps = g_stamps;
+#endif
+    const int maps = a.M / (a.H * a.W), kc = a.C / 32;
+    const long tn = (a.N + BN - 1) / BN;
+    const long ni = (long)(a.H - 2) * (a.W - 2), ne = 2l * (a.W - 2) + 2l * (a.H - 2);
+    int best = 4;
+    double best_t = 1e30;
+    static const int forced_mt = experiment_knob("WD_SPLIT_MT");
+    for (int mt = MT_MAX; mt >= MT_MIN; --mt) {
+        if (forced_mt >= MT_MIN && forced_mt <= MT_MAX && mt != forced_mt) continue;
+        const long nch = (maps + 32 * mt - 1) / (32 * mt);
+        const double eff = (mt == 4 || mt == 5) ? 1.0 : 1.24;
+        auto tile = [&](int taps) { return mt * taps * kc * 0.52 * eff + 2.0 + mt; };
+        const double work = (double)nch * tn * (ni * tile(9) + ne * tile(6) + 4 * tile(4)) / 256.0;
+        const double t = work > tile(9) ? work : tile(9);
+        if (t < best_t * 0.97) { best_t = t; best = mt; }
+    }
+    a.splitk = 1; a.part = nullptr; a.xmap = 0;
+    a.tiles_m = a.H * a.W * ((maps + 32 * best - 1) / (32 * best));
+    a.tiles_n = (int)tn;
+    switch (best) {
+        case 4: return launch<4, 3>(a, stream);
+        case 6: return launch<6, 3>(a, stream);
+        default: return launch<5, 3>(a, stream);
+    }
 }
 
 bool misaligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
@@ -1078,6 +1160,10 @@ int wd_conv_split_f32(const float* x, int batch, int H, int W, int C, const void
     s.a = x; s.w = (const uint4*)packed_w; s.bias = bias; s.residual = residual; s.out = out;
     s.lda = C; s.ldc = N; s.M = (int)M; s.N = N; s.K = ksize * ksize * C; s.relu = relu;
     s.H = H; s.W = W; s.C = C; s.Ho = Ho; s.Wo = Wo; s.stride = stride; s.pad = pad; s.ksize = ksize;
+    // many small maps (the box heads: 1000 ROIs x 7 x 7): position-major tiles skip the taps that fall into the zero padding (MODE 3)
+    static const int no_pm = experiment_knob("WD_SPLIT_NO_POSMAJOR");
+    if (!no_pm && ksize == 3 && stride == 1 && pad == 1 && H >= 3 && W >= 3 && H * W <= 81 && batch >= 256)
+        return dispatch_position_major(s, (hipStream_t)stream_);
     return dispatch<1>(s, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
