@@ -638,10 +638,24 @@ def main():
                 'config': {'workload': res['workload'], 'stage': args.stage, 'parallelism': 'sequence-shard x%d' % world},
                 'roofline': res.get('roofline'), 'cpu_baseline': res.get('cpu_baseline'), 'verified': res.get('verified'),
                 'extra': res.get('extra')}
+        # the JSON line is the LAST thing on stdout: the process group is gone (nothing RCCL prints at tear-down follows it) and what the C libraries
+        # have buffered so far - RCCL's version banner under NCCL_DEBUG=VERSION - is flushed in front of it
+        _finish_dist_and_flush()
         print(json.dumps(line), flush=True)
+    else:
+        _finish_dist_and_flush()
+
+
+def _finish_dist_and_flush():
     if _dist_on():
         import torch.distributed as dist
         dist.destroy_process_group()
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 if __name__ == '__main__':

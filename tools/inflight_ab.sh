@@ -69,5 +69,11 @@ case "$1" in
     run train_posmajor_b --stage train --steps 8 --warmup 4
     WD_SPLIT_NO_POSMAJOR=1 run train_plainrows_b --stage train --steps 8 --warmup 4
     ;;
+  nosplitk)
+    run e2e_planner_a --steps 10 --warmup 3
+    WD_SPLIT_SPLITK=1 run e2e_no_kslices_a --steps 10 --warmup 3
+    run e2e_planner_b --steps 10 --warmup 3
+    WD_SPLIT_SPLITK=1 run e2e_no_kslices_b --steps 10 --warmup 3
+    ;;
   *) run "$@" ;;
 esac
