@@ -629,8 +629,13 @@ def conv_split(x, packed, n_out, ksize, stride=1, pad=0, bias=None, residual=Non
                                             C.c_int(pad), _p(bias), _p(residual), _p(out), C.c_int(n_out), C.c_int(1 if relu else 0), _p(ws), C.c_size_t(ws_bytes),
                                             _stream()),
                'wd_conv_split_f32')
+    k_eff = ksize * ksize * c
+    if ksize == 3 and stride == 1 and pad == 1 and h >= 3 and w >= 3 and h * w <= 81 and b >= 256 and os.environ.get('WD_SPLIT_NO_POSMAJOR') != '1':
+        # position-major tiles (csrc/det_gemm_split.hip MODE 3) SKIP the taps in the zero padding: only the walked taps are matrix work that was issued
+        walked = (h - 2) * (w - 2) * 9 + (2 * (h - 2) + 2 * (w - 2)) * 6 + 4 * 4
+        k_eff = k_eff * walked / float(9 * h * w)
     _split_log_end(ev, 'gemm_split_kernel: %dx%d conv s%d M=%d N=%d K=%d' % (ksize, ksize, stride, b * ho * wo, n_out, ksize * ksize * c), b * ho * wo, n_out,
-                   ksize * ksize * c)
+                   k_eff)
     return out
 
 
