@@ -1,4 +1,6 @@
 #!/bin/bash
+# ARCHIVED (round 6): the WD_ABL compile-time ablation masks of the f32-A kernel left csrc/det_gemm_split.hip with the other laboratory code; this script works at
+# commit 8ca8714 (round 5).  The planes kernel has its own: tools/split_planes_ablation_build.py + tools/split_planes_ablation.sh.
 # Cumulative compile-time ablations of the split-operand ring kernel (timing only; results are wrong by construction):
 #   tools/split_ablation.sh "9600 1024 1024"      (builds csrc/variants/lib_abl<N>.so for the WD_ABL masks below when missing)
 R=${GRAFT_REPO_ROOT:-/root/repo}
