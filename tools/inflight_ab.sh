@@ -75,5 +75,12 @@ case "$1" in
     run e2e_planner_b --steps 10 --warmup 3
     WD_SPLIT_SPLITK=1 run e2e_no_kslices_b --steps 10 --warmup 3
     ;;
+  defer)
+    run e2e_defer_a --steps 10 --warmup 3
+    run e2e_nodefer_a --no-defer-track --steps 10 --warmup 3
+    run e2e_defer_b --steps 10 --warmup 3
+    run e2e_nodefer_b --no-defer-track --steps 10 --warmup 3
+    run detect_only --stage detect --steps 10 --warmup 3
+    ;;
   *) run "$@" ;;
 esac
