@@ -121,7 +121,8 @@ extern "C" int wd_debug_hold(int n_wg, int lds_bytes, long long cycles, int* sin
 // register operands.  kind: 1 v_mfma_f32_32x32x16_bf16 on pseudo-random operands, 2 the same on zeros, 3 v_mfma_f32_32x32x2_f32 on random operands,
 // 4 v_mfma_f32_16x16x32_bf16 random, 5 bf16 32x32x16 with operands of ONE repeated value (no toggling between instructions),
 // 6 = 1 with ONE random A and ONE random B register set (the register footprint of kinds 2 / 5, random data), 7 = 2 (zeros) with 28 extra live registers
-// (the footprint of kind 1, zero data), 8 = 6 with A == B (one random register set for both operands)
+// (the footprint of kind 1, zero data), 8 = 6 with A == B (one random register set for both operands), 9 = 4 (the 16x16x32 form) with ONE random A and ONE
+// random B register set (what a deformable conv on this instruction would issue: a tap's weight fragment against every pixel group)
 namespace {
 using bf16x8_ = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4_ = __attribute__((ext_vector_type(4))) float;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void mfma_burn_kernel(int iters, unsigned* 
         x[i] = __builtin_bit_cast(bf16x8_, *reinterpret_cast<f32x4_*>(u));
         y[i] = __builtin_bit_cast(bf16x8_, *reinterpret_cast<f32x4_*>(v));
     }
-    if (kind == 6 || kind == 8) {
+    if (kind == 6 || kind == 8 || kind == 9) {
 #pragma unroll
         for (int i = 1; i < 4; ++i) { x[i] = x[0]; y[i] = y[0]; }
     }
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void mfma_burn_kernel(int iters, unsigned* 
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4_, x[(i + r) & 3])[0], __builtin_bit_cast(f32x4_, y[i])[0], acc[i], 0, 0, 0);
-        } else if (kind == 4) {
+        } else if (kind == 4 || kind == 9) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
 #pragma unroll
@@ -210,6 +211,7 @@ extern "C" int wd_debug_mfma_burn(int workgroups, int kind, int iters, unsigned*
         case 6: hipLaunchKernelGGL(mfma_burn_kernel<6>, g, b, 0, st, iters, sink); break;
         case 7: hipLaunchKernelGGL(mfma_burn_kernel<7>, g, b, 0, st, iters, sink); break;
         case 8: hipLaunchKernelGGL(mfma_burn_kernel<8>, g, b, 0, st, iters, sink); break;
+        case 9: hipLaunchKernelGGL(mfma_burn_kernel<9>, g, b, 0, st, iters, sink); break;
         default: hipLaunchKernelGGL(mfma_burn_kernel<5>, g, b, 0, st, iters, sink); break;
     }
     WT_HIP(hipGetLastError());
