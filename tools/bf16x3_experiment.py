@@ -50,7 +50,7 @@ def main():
     res = {}
     for mode in ('0', '1'):
         path = '/tmp/bf16x3_%s.pt' % mode
-        env = dict(os.environ, WD_DEFORM_BF16X3=mode)
+        env = dict(os.environ, WD_DEFORM_BF16X3=mode, WT_EXPERIMENT='1')
         subprocess.run([sys.executable, os.path.abspath(__file__), '--child', path], env=env, check=True)
         import torch
         res[mode] = torch.load(path)

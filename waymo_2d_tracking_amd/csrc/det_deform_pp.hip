@@ -724,7 +724,15 @@ int wd_deform_pp_launch(const float* x, const float* offset, const float* packed
     if (nsplit > (ntiles + teams - 1) / teams) nsplit = (ntiles + teams - 1) / teams;       // at least one tile per team
     if (nsplit < 1) nsplit = 1;
     const float* wfrag = packed_weight + (size_t)c * cg * 9;       // lane-major fragment copy (pack_weight_kernel)
-    static const bool bf3 = getenv("WD_DEFORM_BF16X3") && getenv("WD_DEFORM_BF16X3")[0] == '1';     // EXPERIMENT: not fp32 (see the kernel's header)
+    // EXPERIMENT: not fp32 (see the kernel's header), and as an instruction stream (v_mfma_f32_16x16x32_bf16 with a repeated weight operand) the strongest
+    // co-residency aggressor measured (profiles/r06_costream_victim_side.txt, burner kind 9): honoured only together with WT_EXPERIMENT=1
+    static const bool bf3 = []() {
+        const char *e = getenv("WD_DEFORM_BF16X3"), *x = getenv("WT_EXPERIMENT");
+        if (!(e && e[0] == '1')) return false;
+        if (x && x[0] == '1') return true;
+        fprintf(stderr, "libwaymotrack: WD_DEFORM_BF16X3=1 ignored (laboratory switch; set WT_EXPERIMENT=1 to use it)\n");
+        return false;
+    }();
     const dim3 grid((unsigned)(items * nsplit));
     if (wide && cg == 32)
         hipLaunchKernelGGL((deform_conv3x3_pp_kernel<32, false, pp::PS_WIDE, 1>), grid, dim3(256), (pp::smem_bytes<32, pp::PS_WIDE, 1>()), stream, x,
